@@ -1,0 +1,229 @@
+"""ctypes front-end of the CPU oracle (oracle/icp_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, bench.py's cpu_baseline leg and
+__graft_entry__.smoke().  The product package never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libicp_oracle.so")
+
+F_TRIM, F_NORMAL, F_MAXDIST = 1, 2, 4
+
+
+class Filters(C.Structure):
+    _fields_ = [("flags", C.c_int32), ("trim_ratio", C.c_float), ("cos_max_angle", C.c_float),
+                ("outlier_max_d2", C.c_float)]
+
+
+class Params(C.Structure):
+    _fields_ = [("max_dist", C.c_float), ("filt", Filters), ("max_iter", C.c_int32),
+                ("min_diff_rot", C.c_float), ("min_diff_trans", C.c_float), ("smooth_len", C.c_int32),
+                ("fixed_iters", C.c_int32), ("n_threads", C.c_int32)]
+
+
+class Result(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32), ("max_iter_reached", C.c_int32),
+                ("status", C.c_int32), ("n_kept_last", C.c_int64), ("err_last", C.c_double),
+                ("A_last", C.c_float * 36), ("b_last", C.c_float * 6), ("T_iter", C.c_float * 16),
+                ("T_refMean_readMean", C.c_float * 16)]
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (seconds).  Returns the .so path."""
+    src = os.path.join(_HERE, "icp_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "_build/libicp_oracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.orc_kd_build.restype = C.c_void_p
+        _lib.orc_kd_build.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
+        _lib.orc_kd_free.argtypes = [C.c_void_p]
+        _lib.orc_max_threads.restype = C.c_int
+    return _lib
+
+
+def _f32(a, cols=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if cols is not None:
+        assert a.ndim == 2 and a.shape[1] == cols, a.shape
+    return a
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def max_threads() -> int:
+    return lib().orc_max_threads()
+
+
+def centroid(xyz) -> np.ndarray:
+    xyz = _f32(xyz)
+    out = np.zeros(3, np.float32)
+    lib().orc_centroid(_p(xyz), C.c_int64(xyz.shape[1]), C.c_int64(xyz.shape[0]), _p(out))
+    return out
+
+
+class KdTree:
+    def __init__(self, xyz):
+        self.xyz = _f32(xyz)
+        self.h = lib().orc_kd_build(_p(self.xyz), C.c_int64(self.xyz.shape[1]), C.c_int64(self.xyz.shape[0]))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_kd_free(C.c_void_p(self.h))
+            self.h = None
+
+    def knn(self, src_xyz, T, max_dist=math.inf, n_threads=1):
+        src = _f32(src_xyz)
+        T = _f32(T).reshape(16)
+        n = src.shape[0]
+        ids = np.empty(n, np.int32)
+        d2 = np.empty(n, np.float32)
+        lib().orc_knn(C.c_void_p(self.h), _p(src), C.c_int64(src.shape[1]), C.c_int64(n), _p(T),
+                      C.c_float(max_dist), _p(ids), _p(d2), C.c_int(n_threads))
+        return ids, d2
+
+
+def knn_brute(tgt_xyz, src_xyz, T, max_dist=math.inf):
+    tgt, src = _f32(tgt_xyz), _f32(src_xyz)
+    T = _f32(T).reshape(16)
+    n = src.shape[0]
+    ids = np.empty(n, np.int32)
+    d2 = np.empty(n, np.float32)
+    lib().orc_knn_brute(_p(tgt), C.c_int64(tgt.shape[1]), C.c_int64(tgt.shape[0]), _p(src),
+                        C.c_int64(src.shape[1]), C.c_int64(n), _p(T), C.c_float(max_dist), _p(ids), _p(d2))
+    return ids, d2
+
+
+def make_filters(trim_ratio=None, max_normal_angle=None, outlier_max_dist=None) -> Filters:
+    f = Filters(0, 1.0, -1.0, math.inf)
+    if trim_ratio is not None:
+        f.flags |= F_TRIM
+        f.trim_ratio = trim_ratio
+    if max_normal_angle is not None:
+        f.flags |= F_NORMAL
+        f.cos_max_angle = float(np.cos(np.float32(max_normal_angle)))  # cosf in T=float
+    if outlier_max_dist is not None:
+        f.flags |= F_MAXDIST
+        f.outlier_max_d2 = float(np.float32(outlier_max_dist) ** 2)
+    return f
+
+
+def trim_limit(d2, ratio):
+    d2 = _f32(d2)
+    lim = C.c_float()
+    nf = C.c_int64()
+    rc = lib().orc_trim_limit(_p(d2), C.c_int64(d2.shape[0]), C.c_float(ratio), C.byref(lim), C.byref(nf))
+    if rc != 0:
+        raise RuntimeError("ConvergenceError: no matches available for computing distance quantiles")
+    return lim.value, nf.value
+
+
+def weights(filters: Filters, src_nrm, tgt_nrm, T, ids, d2):
+    n = ids.shape[0]
+    w = np.empty(n, np.float32)
+    sn = _f32(src_nrm) if src_nrm is not None else None
+    tn = _f32(tgt_nrm) if tgt_nrm is not None else None
+    T = _f32(T).reshape(16)
+    lim = C.c_float()
+    rc = lib().orc_weights(C.byref(filters), _p(sn), C.c_int64(sn.shape[1] if sn is not None else 3), _p(tn),
+                           C.c_int64(tn.shape[1] if tn is not None else 3), _p(T), _p(ids), _p(_f32(d2)),
+                           C.c_int64(n), _p(w), C.byref(lim))
+    if rc != 0:
+        raise RuntimeError("ConvergenceError: no matches available for computing distance quantiles")
+    return w, lim.value
+
+
+def p2pl_normal_eq(src_xyz, tgt_xyz, tgt_nrm, T, ids, d2, w, n_threads=1):
+    src, tgt, tn = _f32(src_xyz), _f32(tgt_xyz), _f32(tgt_nrm)
+    T = _f32(T).reshape(16)
+    A = np.zeros((6, 6), np.float32)
+    b = np.zeros(6, np.float32)
+    err = C.c_double()
+    kept = C.c_int64()
+    lib().orc_p2pl_normal_eq(_p(src), C.c_int64(src.shape[1]), _p(tgt), C.c_int64(tgt.shape[1]), _p(tn),
+                             C.c_int64(tn.shape[1]), _p(T), _p(ids), _p(_f32(d2)), _p(_f32(w)),
+                             C.c_int64(src.shape[0]), _p(A), _p(b), C.byref(err), C.byref(kept), C.c_int(n_threads))
+    return A, b, err.value, kept.value
+
+
+def solve6(A, b):
+    A, b = _f32(A).reshape(36), _f32(b)
+    x = np.zeros(6, np.float32)
+    lib().orc_solve6.restype = C.c_int
+    rank = lib().orc_solve6(_p(A), _p(b), _p(x))
+    return x, rank
+
+
+def x_to_T(x):
+    T = np.zeros(16, np.float32)
+    lib().orc_x_to_T(_p(_f32(x)), _p(T))
+    return T.reshape(4, 4)
+
+
+def icp_p2pl(tgt_xyz, tgt_nrm, src_xyz, src_nrm=None, T_init=None, *, max_dist=math.inf, trim_ratio=None,
+             max_normal_angle=None, outlier_max_dist=None, max_iter=40, min_diff_rot=0.001, min_diff_trans=0.001,
+             smooth_len=3, fixed_iters=0, n_threads=1):
+    """Full reference-chain registration (R1-R10).  Returns (T 4x4 float32, Result)."""
+    tgt, tn, src = _f32(tgt_xyz), _f32(tgt_nrm), _f32(src_xyz)
+    sn = _f32(src_nrm) if src_nrm is not None else None
+    T0 = _f32(np.eye(4) if T_init is None else T_init).reshape(16)
+    P = Params()
+    P.max_dist = max_dist
+    P.filt = make_filters(trim_ratio, max_normal_angle, outlier_max_dist)
+    P.max_iter, P.min_diff_rot, P.min_diff_trans, P.smooth_len = max_iter, min_diff_rot, min_diff_trans, smooth_len
+    P.fixed_iters, P.n_threads = fixed_iters, n_threads
+    if (P.filt.flags & F_NORMAL) and sn is None:
+        raise ValueError("InvalidField: SurfaceNormalOutlierFilter needs 'normals' on the reading")
+    T = np.zeros(16, np.float32)
+    res = Result()
+    lib().orc_icp_p2pl(_p(tgt), C.c_int64(tgt.shape[1]), _p(tn), C.c_int64(tn.shape[1]), C.c_int64(tgt.shape[0]),
+                       _p(src), C.c_int64(src.shape[1]), _p(sn), C.c_int64(sn.shape[1] if sn is not None else 3),
+                       C.c_int64(src.shape[0]), _p(T0), C.byref(P), _p(T), C.byref(res))
+    return T.reshape(4, 4), res
+
+
+def gicp_normal_eq(src_xyz, src_cov, tgt_xyz, tgt_cov, T, ids):
+    src, tgt = _f32(src_xyz), _f32(tgt_xyz)
+    sc, tc = _f32(src_cov, 6), _f32(tgt_cov, 6)
+    T = _f32(T).reshape(16)
+    H = np.zeros((6, 6), np.float64)
+    b = np.zeros(6, np.float64)
+    e = C.c_double()
+    cnt = C.c_int64()
+    lib().orc_gicp_normal_eq(_p(src), C.c_int64(src.shape[1]), _p(sc), _p(tgt), C.c_int64(tgt.shape[1]), _p(tc),
+                             _p(T), _p(np.ascontiguousarray(ids, np.int32)), C.c_int64(src.shape[0]), _p(H), _p(b),
+                             C.byref(e), C.byref(cnt))
+    return H, b, e.value, cnt.value
+
+
+def icp_gicp(tgt_xyz, tgt_cov, src_xyz, src_cov, T_init=None, *, max_dist=math.inf, max_iter=20, fixed_iters=0,
+             rot_eps=0.1 * math.pi / 180.0, trans_eps=1e-3, n_threads=1):
+    tgt, src = _f32(tgt_xyz), _f32(src_xyz)
+    tc, sc = _f32(tgt_cov, 6), _f32(src_cov, 6)
+    T0 = _f32(np.eye(4) if T_init is None else T_init).reshape(16)
+    T = np.zeros(16, np.float32)
+    res = Result()
+    lib().orc_icp_gicp(_p(tgt), C.c_int64(tgt.shape[1]), _p(tc), C.c_int64(tgt.shape[0]), _p(src),
+                       C.c_int64(src.shape[1]), _p(sc), C.c_int64(src.shape[0]), _p(T0), C.c_float(max_dist),
+                       C.c_int(max_iter), C.c_int(fixed_iters), C.c_double(rot_eps), C.c_double(trans_eps),
+                       C.c_int(n_threads), _p(T), C.byref(res))
+    return T.reshape(4, 4), res
