@@ -1,0 +1,191 @@
+/*
+ * o3dslam_reg.h -- C ABI of the MI355X-native scan-to-map registration path.
+ *
+ * Drop-in boundary for the ONE hot path of leggedrobotics/open3d_slam_private:
+ *   B2  PointMatcher<float>::ICP::initReference / compute
+ *         libpointmatcher/pointmatcher/PointMatcher.h:1036-1042, ICP.cpp:813-898,902-1349
+ *         called from open3d_slam/src/Mapper.cpp:343,372-373
+ *   B1  o3d_slam::CloudRegistration::registerClouds (GICP operator)
+ *         open3d_slam/include/open3d_slam/CloudRegistration.hpp:19-73, src/CloudRegistration.cpp:16-21
+ * (paths relative to the reference tree).  Plain pointers and sizes only; no C++,
+ * torch or Eigen types cross this boundary; no exception crosses it -- every throw
+ * site of the reference maps to a reg_status code.
+ *
+ * LAYOUT CONTRACT
+ *  - points:  `xyz` + `xyz_stride` (in floats).  stride 4 == libpointmatcher's
+ *    DataPoints::features (Eigen column-major (dim+1) x N float => {x,y,z,1} per point,
+ *    PointMatcher.h:176,375); stride 3 == packed xyz.  The 4th component is ignored
+ *    (assumed 1).
+ *  - normals: `nrm` + `nrm_stride` (3 == the `normals` descriptor rows, packed).
+ *  - covariances (GICP): 6 floats per point, (xx, xy, xz, yy, yz, zz).
+ *  - 4x4 transforms are COLUMN-major float[16] (T[c*4+r]) == Eigen::Matrix4f::data()
+ *    of PointMatcher<float>::TransformationParameters; reading -> reference.
+ *  - `on_device` != 0: the pointers are HIP device pointers on the handle's device
+ *    (no PCIe copy); == 0: host pointers (copied with hipMemcpyAsync).
+ *
+ * THREADING: one handle == one non-re-entrant registration context (like the single
+ * `icp_` member of o3d_slam::Mapper, Mapper.hpp:72, serialised by mapManipulationMutex_).
+ * Independent handles may be used concurrently, each on its own HIP stream.
+ */
+#ifndef O3DSLAM_REG_H
+#define O3DSLAM_REG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define REG_API __attribute__((visibility("default")))
+
+typedef struct reg_handle reg_handle;
+
+/* Status codes; each names the reference behaviour it replaces. */
+typedef enum {
+    REG_OK = 0,
+    REG_EMPTY_TARGET = 1,        /* initReference() returns false            ICP.cpp:850-855 */
+    REG_EMPTY_SOURCE = 2,        /* runtime_error "reading point cloud is empty" ICP.cpp:958-960 */
+    REG_NO_CORRESPONDENCES = 3,  /* ConvergenceError  ErrorMinimizer.cpp:75-77, Matches.cpp:76-80 */
+    REG_BAD_TRANSFORM = 4,       /* runtime_error / TransformationError      ICP.cpp:910-918 */
+    REG_NOT_CONFIGURED = 5,      /* "You must setup a matcher ..."           ICP.cpp:819-824; no target/source set */
+    REG_BAD_ARGUMENT = 6,        /* InvalidParameter                         Registrar.h:103-109 */
+    REG_MISSING_FIELD = 7,       /* InvalidField: no `normals` descriptor    DataPoints.cpp:1112 */
+    REG_DEVICE_ERROR = 8,        /* HIP runtime failure (no reference analogue); the product never falls back to CPU */
+    REG_UNSUPPORTED = 9
+} reg_status;
+
+typedef enum {
+    REG_COST_P2PL = 0, /* PointToPlaneErrorMinimizer   ICP.cpp:1512-1566 + ErrorMinimizers/PointToPlane.cpp:274-400 */
+    REG_COST_GICP = 1  /* plane-to-plane GICP factor (north star; arithmetic not in the reference tree) */
+} reg_cost;
+
+/* Configuration == the hot-path subset of param/icp.yaml (open3d_slam_ros/param/icp.yaml:11-27,86-92). */
+typedef struct {
+    int32_t struct_size;        /* = sizeof(reg_params); checked */
+    int32_t cost;               /* reg_cost */
+    /* matcher: KDTreeMatcher (MatchersImpl.h:80-88) */
+    int32_t knn;                /* must be 1 */
+    float   max_dist;           /* maxDist; INFINITY allowed (default of the reference) */
+    float   epsilon;            /* accepted for config compatibility; the search is always exact (epsilon = 0) */
+    /* outlierFilters (OutlierFiltersImpl.cpp); chain = product of 0/1 weights */
+    int32_t use_trimmed;        /* TrimmedDistOutlierFilter */
+    float   trim_ratio;
+    int32_t use_surface_normal; /* SurfaceNormalOutlierFilter */
+    float   max_normal_angle;   /* rad */
+    int32_t use_max_dist_filter;/* MaxDistOutlierFilter */
+    float   outlier_max_dist;
+    /* transformationCheckers (TransformationCheckersImpl.cpp:57-158) */
+    int32_t max_iter;           /* CounterTransformationChecker.maxIterationCount */
+    float   min_diff_rot;       /* DifferentialTransformationChecker */
+    float   min_diff_trans;
+    int32_t smooth_len;
+    int32_t fixed_iters;        /* >0: run exactly this many iterations, checkers ignored (throughput runs) */
+    /* GICP termination (Gauss-Newton, rotation-first tangent) */
+    float   gicp_rot_eps;       /* rad */
+    float   gicp_trans_eps;     /* m */
+    /* device-side search structure */
+    float   cell_size;          /* voxel-bin edge in metres; 0 = choose from target density */
+    int32_t device;             /* HIP device ordinal */
+    int32_t sort_source;        /* 1: Morton-order the reading on upload (speed only; results in input order) */
+    int32_t reserved[7];
+} reg_params;
+
+typedef struct {
+    int32_t iterations;
+    int32_t converged;          /* DifferentialTransformationChecker said stop */
+    int32_t max_iter_reached;   /* CounterTransformationChecker threw MaxNumIterationsReached (ICP.cpp:1294-1298) */
+    int32_t rank_last;          /* numerical rank of the last 6x6 system (6 = invertible) */
+    int64_t n_inliers;          /* pairs with non-zero weight in the last iteration */
+    int64_t n_matched;          /* pairs with a neighbour inside max_dist in the last iteration */
+    double  error;              /* P2PL: sum w r^2;  GICP: sum 0.5 r^T M r  (last iteration) */
+    double  fitness;            /* n_inliers / N   (open3d RegistrationResult::fitness_ analogue) */
+    double  inlier_rmse;        /* sqrt(sum_inliers d^2 / n_inliers) */
+    float   H_last[36];         /* last normal matrix, row-major (symmetric) */
+    float   b_last[6];
+    float   target_build_ms;    /* last reg_set_target: upload + voxel-bin build */
+    float   loop_ms;            /* iteration loop of the last reg_register (device time, HIP events) */
+} reg_result;
+
+/* ICPChainBase::setDefault (ICP.cpp:100-113): knn 1, eps 0, maxDist inf, Trimmed 0.85,
+   Counter 40, Differential 0.001/0.001/3, point-to-plane. */
+REG_API void reg_default_params(reg_params* p);
+/* open3d_slam_ros/param/icp.yaml as shipped (maxDist 0.5, Trimmed 0.9, SurfaceNormal 1.57,
+   Differential 0.001/0.008/3, Counter 30); epsilon is forced to 0 (exact search). */
+REG_API void reg_shipped_params(reg_params* p);
+
+REG_API reg_status reg_create(const reg_params* p, reg_handle** out);
+REG_API void       reg_destroy(reg_handle* h);
+REG_API const char* reg_last_error(const reg_handle* h);
+
+/* All device work of the handle is enqueued on this hipStream_t (default: a stream the handle owns). */
+REG_API reg_status reg_set_stream(reg_handle* h, void* hip_stream);
+
+/* == ICP::initReference (ICP.cpp:847-898): copy, subtract centroid, build the search structure
+   (voxel-bin table replaces KDTreeMatcher::init, MatchersImpl.cpp:78-83).
+   P2PL needs `nrm`; GICP needs `cov`. */
+REG_API reg_status reg_set_target(reg_handle* h, const float* xyz, int64_t xyz_stride, const float* nrm,
+                                  int64_t nrm_stride, const float* cov, int64_t m, int on_device);
+
+/* Reading cloud of the next reg_register / reg_prepare (ICP.cpp:952).  `nrm` is required when
+   use_surface_normal is set (else REG_MISSING_FIELD); `cov` is required for GICP. */
+REG_API reg_status reg_set_source(reg_handle* h, const float* xyz, int64_t xyz_stride, const float* nrm,
+                                  int64_t nrm_stride, const float* cov, int64_t n, int on_device);
+
+/* == ICP::compute(reading, -, T_init, false) (ICP.cpp:813-844 -> 902-1349) on the reading given to
+   reg_set_source: R2 reading prep, the while(iterate) loop (R3-R9) on the device, R10 composition. */
+REG_API reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], reg_result* res);
+
+/* Convenience == reg_set_source + reg_register. */
+REG_API reg_status reg_compute(reg_handle* h, const float* xyz, int64_t xyz_stride, const float* nrm,
+                               int64_t nrm_stride, const float* cov, int64_t n, int on_device,
+                               const float T_init[16], float T_out[16], reg_result* res);
+
+/* Factor-level hook (one pass of R3-R7, "Factor::linearize + reduction").
+   reg_prepare does R2 for T_init (P2PL: centre + pre-transform the reading; GICP: no-op besides upload).
+   reg_linearize evaluates the cost at T_iter (P2PL: transform in the centred frames, identity at
+   iteration 0; GICP: full reading->reference transform) and returns the reduced system:
+   P2PL: H = A, b as in ICP.cpp:1543,1565 (x = [rx ry rz tx ty tz]);  GICP: H = sum J^T M J, b = sum J^T M r. */
+REG_API reg_status reg_prepare(reg_handle* h, const float T_init[16]);
+REG_API reg_status reg_linearize(reg_handle* h, const float T_iter[16], float H[36], float b[6], double* err,
+                                 int64_t* n_inliers);
+
+/* Correspondences of the most recent iteration / linearize, in the reading's input order:
+   ids = index into the target as given to reg_set_target (-1 = none within max_dist), d2 = squared
+   distance (+inf = none) (PointMatcher.h:416-436), w = outlier weight (0/1).  Any pointer may be NULL. */
+REG_API reg_status reg_get_correspondences(reg_handle* h, int32_t* ids, float* d2, float* w);
+
+/* Distributed (point-partitioned reading) support: the per-iteration reduction is exposed in two
+   halves so the caller can sum the partial systems of all ranks (RCCL all-reduce over xGMI) in between.
+   reg_match_local     : R3+R4 on this rank's slice; fills hist[2048] with the level-`level` radix histogram
+                         of finite d2 (level 0..2; prefix = bits fixed by previous levels).
+   reg_reduce_local    : R5-R7 given the global trim limit -> 32 doubles {21 upper-tri H, 6 b, err, n_in, n_matched, sum d2 inliers, pad}.
+   reg_apply_update    : R8+R9 from the globally summed 32 doubles (identical on every rank). */
+REG_API reg_status reg_match_local(reg_handle* h, const float T_iter[16]);
+REG_API reg_status reg_trim_histogram(reg_handle* h, int level, uint32_t prefix, uint32_t hist[2048]);
+REG_API reg_status reg_reduce_local(reg_handle* h, const float T_iter[16], float trim_limit, double sums[32]);
+REG_API reg_status reg_solve_update(const reg_params* p, const double sums[32], const float T_iter[16],
+                                    float T_next[16], int32_t* rank);
+
+/* Host-side pieces of the path, exported so they can be checked without a GPU
+   (PointToPlane.cpp:112-265 solve, :327-381 x -> 4x4; column-major 4x4). */
+REG_API int  reg_host_solve6(const float A[36], const float b[6], float x[6]);
+REG_API void reg_host_x_to_T(const float x[6], float T[16]);
+REG_API void reg_host_centroid(const float* xyz, int64_t stride, int64_t n, float out[3]);
+
+/* Introspection of the search structure (tests, DESIGN.md numbers). */
+typedef struct {
+    int64_t n_points;
+    int64_t n_bricks;
+    int64_t n_cells_occupied;
+    int64_t table_bytes;
+    float   cell_size;
+    float   origin[3];
+    float   centroid[3];
+    int32_t dims[3];
+} reg_target_info;
+REG_API reg_status reg_get_target_info(const reg_handle* h, reg_target_info* info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* O3DSLAM_REG_H */

@@ -1,0 +1,291 @@
+"""ctypes binding of include/o3dslam_reg.h (the drop-in C ABI).  No torch types; numpy or raw
+device pointers only.  Mirrors the header 1:1 -- see the header for the reference file:line each
+entry point replaces."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "lib", "libo3dslam_reg.so")
+
+STATUS_NAMES = {0: "OK", 1: "EMPTY_TARGET", 2: "EMPTY_SOURCE", 3: "NO_CORRESPONDENCES", 4: "BAD_TRANSFORM",
+                5: "NOT_CONFIGURED", 6: "BAD_ARGUMENT", 7: "MISSING_FIELD", 8: "DEVICE_ERROR", 9: "UNSUPPORTED"}
+COST_P2PL, COST_GICP = 0, 1
+
+
+class RegError(RuntimeError):
+    def __init__(self, status, msg=""):
+        self.status = status
+        super().__init__(f"{STATUS_NAMES.get(status, status)}: {msg}")
+
+
+class RegParams(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("cost", C.c_int32), ("knn", C.c_int32), ("max_dist", C.c_float),
+                ("epsilon", C.c_float), ("use_trimmed", C.c_int32), ("trim_ratio", C.c_float),
+                ("use_surface_normal", C.c_int32), ("max_normal_angle", C.c_float),
+                ("use_max_dist_filter", C.c_int32), ("outlier_max_dist", C.c_float), ("max_iter", C.c_int32),
+                ("min_diff_rot", C.c_float), ("min_diff_trans", C.c_float), ("smooth_len", C.c_int32),
+                ("fixed_iters", C.c_int32), ("gicp_rot_eps", C.c_float), ("gicp_trans_eps", C.c_float),
+                ("cell_size", C.c_float), ("device", C.c_int32), ("sort_source", C.c_int32),
+                ("reserved", C.c_int32 * 7)]
+
+
+class RegResult(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32), ("max_iter_reached", C.c_int32),
+                ("rank_last", C.c_int32), ("n_inliers", C.c_int64), ("n_matched", C.c_int64), ("error", C.c_double),
+                ("fitness", C.c_double), ("inlier_rmse", C.c_double), ("H_last", C.c_float * 36),
+                ("b_last", C.c_float * 6), ("target_build_ms", C.c_float), ("loop_ms", C.c_float)]
+
+
+class TargetInfo(C.Structure):
+    _fields_ = [("n_points", C.c_int64), ("n_bricks", C.c_int64), ("n_cells_occupied", C.c_int64),
+                ("table_bytes", C.c_int64), ("cell_size", C.c_float), ("origin", C.c_float * 3),
+                ("centroid", C.c_float * 3), ("dims", C.c_int32 * 3)]
+
+
+EXPORTS = ["reg_default_params", "reg_shipped_params", "reg_create", "reg_destroy", "reg_last_error",
+           "reg_set_stream", "reg_set_target", "reg_set_source", "reg_register", "reg_compute", "reg_prepare",
+           "reg_linearize", "reg_get_correspondences", "reg_match_local", "reg_trim_histogram", "reg_reduce_local",
+           "reg_solve_update", "reg_host_solve6", "reg_host_x_to_T", "reg_host_centroid", "reg_get_target_info"]
+
+
+def lib_path() -> str:
+    return _SO
+
+
+def build_library(force: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    cmd = ["make", "-C", src_dir]
+    if force:
+        cmd.append("-B")
+    subprocess.check_call(cmd)
+    return _SO
+
+
+_lib = None
+
+
+def load_library():
+    """Load the HIP extension; fails loudly when it has not been built (no fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise ImportError(f"{_SO} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the registration path.")
+    lib = C.CDLL(_SO)
+    vp, i64, f32p = C.c_void_p, C.c_int64, C.c_void_p
+    lib.reg_create.argtypes = [C.POINTER(RegParams), C.POINTER(vp)]
+    lib.reg_destroy.argtypes = [vp]
+    lib.reg_last_error.argtypes = [vp]
+    lib.reg_last_error.restype = C.c_char_p
+    lib.reg_set_stream.argtypes = [vp, vp]
+    lib.reg_set_target.argtypes = [vp, f32p, i64, f32p, i64, f32p, i64, C.c_int]
+    lib.reg_set_source.argtypes = [vp, f32p, i64, f32p, i64, f32p, i64, C.c_int]
+    lib.reg_register.argtypes = [vp, f32p, f32p, C.POINTER(RegResult)]
+    lib.reg_compute.argtypes = [vp, f32p, i64, f32p, i64, f32p, i64, C.c_int, f32p, f32p, C.POINTER(RegResult)]
+    lib.reg_prepare.argtypes = [vp, f32p]
+    lib.reg_linearize.argtypes = [vp, f32p, f32p, f32p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    lib.reg_get_correspondences.argtypes = [vp, vp, vp, vp]
+    lib.reg_match_local.argtypes = [vp, f32p]
+    lib.reg_trim_histogram.argtypes = [vp, C.c_int, C.c_uint32, vp]
+    lib.reg_reduce_local.argtypes = [vp, f32p, C.c_float, vp]
+    lib.reg_solve_update.argtypes = [C.POINTER(RegParams), vp, f32p, f32p, C.POINTER(C.c_int32)]
+    lib.reg_host_solve6.argtypes = [f32p, f32p, f32p]
+    lib.reg_host_solve6.restype = C.c_int
+    lib.reg_host_x_to_T.argtypes = [f32p, f32p]
+    lib.reg_host_centroid.argtypes = [f32p, i64, i64, f32p]
+    lib.reg_get_target_info.argtypes = [vp, C.POINTER(TargetInfo)]
+    for name in EXPORTS:
+        getattr(lib, name)  # AttributeError if the library does not export what the header declares
+    _lib = lib
+    return lib
+
+
+def default_params() -> RegParams:
+    p = RegParams()
+    load_library().reg_default_params(C.byref(p))
+    return p
+
+
+def shipped_params() -> RegParams:
+    p = RegParams()
+    load_library().reg_shipped_params(C.byref(p))
+    return p
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _T_in(T):
+    """numpy 4x4 (math layout) -> column-major float[16] as the ABI wants (== Eigen::Matrix4f::data())."""
+    T = np.asarray(T, dtype=np.float32).reshape(4, 4)
+    return np.ascontiguousarray(T.T).reshape(16)
+
+
+def _T_out(buf):
+    return np.array(buf, dtype=np.float32).reshape(4, 4).T.copy()
+
+
+class Registration:
+    """One registration context (== one reg_handle)."""
+
+    def __init__(self, params: RegParams | None = None, **overrides):
+        self._lib = load_library()
+        p = params if params is not None else default_params()
+        for k, v in overrides.items():
+            if not hasattr(p, k):
+                raise TypeError(f"unknown parameter {k}")
+            setattr(p, k, v)
+        p.struct_size = C.sizeof(RegParams)
+        self.params = p
+        self._h = C.c_void_p()
+        st = self._lib.reg_create(C.byref(p), C.byref(self._h))
+        if st != 0:
+            msg = self._lib.reg_last_error(self._h).decode() if self._h else "reg_create rejected the parameters"
+            if self._h:
+                self._lib.reg_destroy(self._h)
+                self._h = C.c_void_p()
+            raise RegError(st, msg)
+        self._keep = []
+        self.n_source = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.reg_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st):
+        if st != 0:
+            raise RegError(st, self._lib.reg_last_error(self._h).decode())
+
+    def set_stream(self, hip_stream: int):
+        self._check(self._lib.reg_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    # ---- host (numpy) entry points ------------------------------------------------------------
+    def set_target(self, xyz, normals=None, covs=None):
+        xyz = _f32(xyz)
+        nrm = _f32(normals) if normals is not None else None
+        cov = _f32(covs) if covs is not None else None
+        m = xyz.shape[0] if xyz.ndim == 2 else 0
+        self._check(self._lib.reg_set_target(self._h, _ptr(xyz), xyz.shape[1] if xyz.ndim == 2 else 3, _ptr(nrm),
+                                             nrm.shape[1] if nrm is not None else 3, _ptr(cov), m, 0))
+
+    def set_source(self, xyz, normals=None, covs=None):
+        xyz = _f32(xyz)
+        nrm = _f32(normals) if normals is not None else None
+        cov = _f32(covs) if covs is not None else None
+        n = xyz.shape[0] if xyz.ndim == 2 else 0
+        self._check(self._lib.reg_set_source(self._h, _ptr(xyz), xyz.shape[1] if xyz.ndim == 2 else 3, _ptr(nrm),
+                                             nrm.shape[1] if nrm is not None else 3, _ptr(cov), n, 0))
+        self.n_source = n
+
+    # ---- device-pointer entry points (inputs already resident in HBM) ---------------------------
+    def set_target_device(self, xyz_ptr, xyz_stride, m, nrm_ptr=None, nrm_stride=3, cov_ptr=None):
+        self._check(self._lib.reg_set_target(self._h, C.c_void_p(xyz_ptr), xyz_stride,
+                                             C.c_void_p(nrm_ptr) if nrm_ptr else None, nrm_stride,
+                                             C.c_void_p(cov_ptr) if cov_ptr else None, m, 1))
+
+    def set_source_device(self, xyz_ptr, xyz_stride, n, nrm_ptr=None, nrm_stride=3, cov_ptr=None):
+        self._check(self._lib.reg_set_source(self._h, C.c_void_p(xyz_ptr), xyz_stride,
+                                             C.c_void_p(nrm_ptr) if nrm_ptr else None, nrm_stride,
+                                             C.c_void_p(cov_ptr) if cov_ptr else None, n, 1))
+        self.n_source = n
+
+    def register(self, T_init=None):
+        Ti = _T_in(np.eye(4) if T_init is None else T_init)
+        To = np.zeros(16, np.float32)
+        res = RegResult()
+        st = self._lib.reg_register(self._h, _ptr(Ti), _ptr(To), C.byref(res))
+        self.last_result = res
+        self._check(st)
+        return _T_out(To), res
+
+    def prepare(self, T_init=None):
+        Ti = _T_in(np.eye(4) if T_init is None else T_init)
+        self._check(self._lib.reg_prepare(self._h, _ptr(Ti)))
+
+    def linearize(self, T_iter=None):
+        Ti = _T_in(np.eye(4) if T_iter is None else T_iter)
+        H = np.zeros(36, np.float32)
+        b = np.zeros(6, np.float32)
+        err = C.c_double()
+        cnt = C.c_int64()
+        self._check(self._lib.reg_linearize(self._h, _ptr(Ti), _ptr(H), _ptr(b), C.byref(err), C.byref(cnt)))
+        return H.reshape(6, 6), b, err.value, cnt.value
+
+    def correspondences(self, want_w=True):
+        n = self.n_source
+        ids = np.empty(n, np.int32)
+        d2 = np.empty(n, np.float32)
+        w = np.empty(n, np.float32) if want_w else None
+        self._check(self._lib.reg_get_correspondences(self._h, _ptr(ids), _ptr(d2), _ptr(w)))
+        return ids, d2, w
+
+    def target_info(self) -> TargetInfo:
+        info = TargetInfo()
+        self._check(self._lib.reg_get_target_info(self._h, C.byref(info)))
+        return info
+
+    # ---- distributed halves ---------------------------------------------------------------------
+    def match_local(self, T_iter):
+        self._check(self._lib.reg_match_local(self._h, _ptr(_T_in(T_iter))))
+
+    def trim_histogram(self, level, prefix=0):
+        hist = np.zeros(2048, np.uint32)
+        self._check(self._lib.reg_trim_histogram(self._h, level, prefix, _ptr(hist)))
+        return hist
+
+    def reduce_local(self, T_iter, trim_limit=math.inf):
+        sums = np.zeros(32, np.float64)
+        self._check(self._lib.reg_reduce_local(self._h, _ptr(_T_in(T_iter)), trim_limit, _ptr(sums)))
+        return sums
+
+
+def solve_update(params: RegParams, sums, T_iter):
+    """R8 + T_iter update on the host (identical on every rank)."""
+    lib = load_library()
+    s = np.ascontiguousarray(sums, np.float64)
+    To = np.zeros(16, np.float32)
+    rank = C.c_int32()
+    st = lib.reg_solve_update(C.byref(params), _ptr(s), _ptr(_T_in(T_iter)), _ptr(To), C.byref(rank))
+    if st != 0:
+        raise RegError(st, "reg_solve_update")
+    return _T_out(To), rank.value
+
+
+def host_solve6(A, b):
+    x = np.zeros(6, np.float32)
+    rank = load_library().reg_host_solve6(_ptr(_f32(A).reshape(36)), _ptr(_f32(b)), _ptr(x))
+    return x, rank
+
+
+def host_x_to_T(x):
+    T = np.zeros(16, np.float32)
+    load_library().reg_host_x_to_T(_ptr(_f32(x)), _ptr(T))
+    return _T_out(T)
+
+
+def host_centroid(xyz):
+    xyz = _f32(xyz)
+    out = np.zeros(3, np.float32)
+    load_library().reg_host_centroid(_ptr(xyz), xyz.shape[1], xyz.shape[0], _ptr(out))
+    return out

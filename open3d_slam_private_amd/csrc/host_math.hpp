@@ -1,0 +1,303 @@
+// host_math.hpp -- host-side (CPU) pieces of the registration path: 4x4 fp32 algebra, the
+// 6x6 solve, x -> SE(3), the transformation checkers.  Product code (not the oracle).
+//
+// Reference behaviour restated (paths relative to the reference tree):
+//   solve      libpointmatcher/pointmatcher/ErrorMinimizers/PointToPlane.cpp:112-265
+//   x -> T     PointToPlane.cpp:327-381   (angle = atan(|w|), axis = w/|w|, t = x[3..5])
+//   checkers   TransformationCheckersImpl.cpp:57-158
+//   frames     ICP.cpp:883-890, 966-984, 1345
+// All 4x4 matrices in this file are ROW-major float[16]; the C ABI converts from/to column-major.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+namespace o3dreg {
+
+inline void m4_identity(float* T) {
+    std::memset(T, 0, 16 * sizeof(float));
+    T[0] = T[5] = T[10] = T[15] = 1.f;
+}
+
+// C = A*B with one rounding per operation, k = 0..3 in order (numeric contract NC3).
+inline void m4_mul(const float* A, const float* B, float* C) {
+    float R[16];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            volatile float s = A[4 * i] * B[j];
+            volatile float t = A[4 * i + 1] * B[4 + j];
+            s = s + t;
+            t = A[4 * i + 2] * B[8 + j];
+            s = s + t;
+            t = A[4 * i + 3] * B[12 + j];
+            s = s + t;
+            R[4 * i + j] = s;
+        }
+    std::memcpy(C, R, sizeof(R));
+}
+
+inline void m4_transpose(const float* A, float* B) {
+    float R[16];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) R[4 * i + j] = A[4 * j + i];
+    std::memcpy(B, R, sizeof(R));
+}
+
+inline bool m4_is_finite(const float* T) {
+    for (int i = 0; i < 16; ++i)
+        if (!std::isfinite(T[i])) return false;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 6x6 symmetric solve, fp64.  Full rank -> LDL^T with diagonal pivoting; rank deficient (pivot test
+// with the fp32 threshold size*eps_f32 of fullPivHouseholderQr::isInvertible) -> minimum-norm
+// solution through a Jacobi eigen-decomposition.  Returns the numerical rank.
+// ---------------------------------------------------------------------------------------------
+inline void jacobi_eig_sym(int n, double* A, double* V, double* lam) {
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) V[i * n + j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 64; ++sweep) {
+        double off = 0;
+        for (int i = 0; i < n; ++i)
+            for (int j = i + 1; j < n; ++j) off += A[i * n + j] * A[i * n + j];
+        if (off < 1e-300) break;
+        for (int p = 0; p < n; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = A[p * n + q];
+                if (std::fabs(apq) < 1e-300) continue;
+                const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < n; ++k) {
+                    const double akp = A[k * n + p], akq = A[k * n + q];
+                    A[k * n + p] = c * akp - s * akq;
+                    A[k * n + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double apk = A[p * n + k], aqk = A[q * n + k];
+                    A[p * n + k] = c * apk - s * aqk;
+                    A[q * n + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double vkp = V[k * n + p], vkq = V[k * n + q];
+                    V[k * n + p] = c * vkp - s * vkq;
+                    V[k * n + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    for (int i = 0; i < n; ++i) lam[i] = A[i * n + i];
+}
+
+// rel_thr: eigenvalues <= rel_thr * max are treated as zero.
+inline int solve_sym6(const double* H, const double* g, double* x, double rel_thr) {
+    double M[36], V[36], lam[6];
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) M[6 * i + j] = 0.5 * (H[6 * i + j] + H[6 * j + i]);
+    jacobi_eig_sym(6, M, V, lam);
+    double lmax = 0;
+    for (int k = 0; k < 6; ++k) lmax = std::fmax(lmax, std::fabs(lam[k]));
+    int rank = 0;
+    for (int i = 0; i < 6; ++i) x[i] = 0;
+    for (int k = 0; k < 6; ++k) {
+        if (!(std::fabs(lam[k]) > lmax * rel_thr)) continue;
+        ++rank;
+        double vb = 0;
+        for (int i = 0; i < 6; ++i) vb += V[6 * i + k] * g[i];
+        vb /= lam[k];
+        for (int i = 0; i < 6; ++i) x[i] += V[6 * i + k] * vb;
+    }
+    return rank;
+}
+
+inline int solve6_p2pl(const float* A, const float* b, float* x) {
+    double H[36], g[6], xd[6];
+    for (int i = 0; i < 36; ++i) H[i] = A[i];
+    for (int i = 0; i < 6; ++i) g[i] = b[i];
+    const int rank = solve_sym6(H, g, xd, 6.0 * 1.1920929e-07);
+    for (int i = 0; i < 6; ++i) x[i] = (float)xd[i];
+    return rank;
+}
+
+// x = [rx ry rz tx ty tz] -> row-major 4x4, fp32, one rounding per op (NC10).
+inline void x_to_T(const float* x, float* T) {
+    volatile float a = x[0] * x[0], b = x[1] * x[1], c = x[2] * x[2];
+    volatile float s = a + b;
+    s = s + c;
+    const float nrm = std::sqrt((float)s);
+    const float angle = std::atan(nrm);
+    float ax[3] = {x[0], x[1], x[2]};
+    const float w = std::fmax(std::fabs(x[0]), std::fmax(std::fabs(x[1]), std::fabs(x[2])));
+    const float y0 = x[0] / w, y1 = x[1] / w, y2 = x[2] / w;
+    volatile float z = y0 * y0, z1 = y1 * y1;
+    z = z + z1;
+    z1 = y2 * y2;
+    z = z + z1;
+    if (z > 0.f) {
+        volatile float d = std::sqrt((float)z);
+        d = d * w;
+        ax[0] = x[0] / d;
+        ax[1] = x[1] / d;
+        ax[2] = x[2] / d;
+    }
+    const float sn = std::sin(angle), cs = std::cos(angle);
+    volatile float sa0 = sn * ax[0], sa1 = sn * ax[1], sa2 = sn * ax[2];
+    const float c1 = 1.0f - cs;
+    volatile float ca0 = c1 * ax[0], ca1 = c1 * ax[1], ca2 = c1 * ax[2];
+    float R[9];
+    volatile float t;
+    t = ca0 * ax[1];
+    R[1] = t - sa2;
+    R[3] = t + sa2;
+    t = ca0 * ax[2];
+    R[2] = t + sa1;
+    R[6] = t - sa1;
+    t = ca1 * ax[2];
+    R[5] = t - sa0;
+    R[7] = t + sa0;
+    t = ca0 * ax[0];
+    R[0] = t + cs;
+    t = ca1 * ax[1];
+    R[4] = t + cs;
+    t = ca2 * ax[2];
+    R[8] = t + cs;
+    bool bad = false;
+    for (int i = 0; i < 9; ++i) bad |= (R[i] != R[i]);
+    for (int i = 3; i < 6; ++i) bad |= (x[i] != x[i]);
+    m4_identity(T);
+    if (!bad)
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) T[4 * i + j] = R[3 * i + j];
+    T[3] = x[3];
+    T[7] = x[4];
+    T[11] = x[5];
+}
+
+// SE(3) exponential (rotation first), fp64, row-major.
+inline void se3_exp(const double* d, double* T) {
+    const double w[3] = {d[0], d[1], d[2]}, v[3] = {d[3], d[4], d[5]};
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], th = std::sqrt(th2);
+    double A, B, C;
+    if (th < 1e-10) {
+        A = 1.0 - th2 / 6.0;
+        B = 0.5 - th2 / 24.0;
+        C = 1.0 / 6.0 - th2 / 120.0;
+    } else {
+        A = std::sin(th) / th;
+        B = (1 - std::cos(th)) / th2;
+        C = (1 - A) / th2;
+    }
+    const double K[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+    double K2[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += K[3 * i + k] * K[3 * k + j];
+            K2[3 * i + j] = s;
+        }
+    std::memset(T, 0, 16 * sizeof(double));
+    T[15] = 1;
+    for (int i = 0; i < 3; ++i) {
+        double t = 0;
+        for (int j = 0; j < 3; ++j) {
+            T[4 * i + j] = (i == j ? 1.0 : 0.0) + A * K[3 * i + j] + B * K2[3 * i + j];
+            t += ((i == j ? 1.0 : 0.0) + B * K[3 * i + j] + C * K2[3 * i + j]) * v[j];
+        }
+        T[4 * i + 3] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Transformation checkers (TransformationCheckersImpl.cpp:57-158)
+// ---------------------------------------------------------------------------------------------
+inline void rot_to_quat(const float* T, float* q /* w x y z */) {
+    const float m00 = T[0], m11 = T[5], m22 = T[10];
+    const float tr = m00 + m11 + m22;
+    if (tr > 0.f) {
+        float t = std::sqrt(tr + 1.0f);
+        q[0] = 0.5f * t;
+        t = 0.5f / t;
+        q[1] = (T[9] - T[6]) * t;
+        q[2] = (T[2] - T[8]) * t;
+        q[3] = (T[4] - T[1]) * t;
+    } else {
+        int i = 0;
+        if (m11 > m00) i = 1;
+        if (m22 > T[5 * i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        float t = std::sqrt(T[5 * i] - T[5 * j] - T[5 * k] + 1.0f);
+        float v[3];
+        v[i] = 0.5f * t;
+        t = 0.5f / t;
+        q[0] = (T[4 * k + j] - T[4 * j + k]) * t;
+        v[j] = (T[4 * j + i] + T[4 * i + j]) * t;
+        v[k] = (T[4 * k + i] + T[4 * i + k]) * t;
+        q[1] = v[0];
+        q[2] = v[1];
+        q[3] = v[2];
+    }
+}
+
+inline float quat_angular_distance(const float* a, const float* b) {
+    const float bw = b[0], bx = -b[1], by = -b[2], bz = -b[3];
+    const float w = a[0] * bw - a[1] * bx - a[2] * by - a[3] * bz;
+    const float x = a[0] * bx + a[1] * bw + a[2] * bz - a[3] * by;
+    const float y = a[0] * by + a[2] * bw + a[3] * bx - a[1] * bz;
+    const float z = a[0] * bz + a[3] * bw + a[1] * by - a[2] * bx;
+    return 2.0f * std::atan2(std::sqrt(x * x + y * y + z * z), std::fabs(w));
+}
+
+struct Checkers {
+    int max_iter = 40;
+    float min_diff_rot = 1e-3f, min_diff_trans = 1e-3f;
+    int smooth_len = 3;
+    std::vector<float> quats, trans;
+    int count = 0;
+    bool converged = false, max_iter_reached = false;
+
+    void init(const float* T) {
+        quats.clear();
+        trans.clear();
+        count = 0;
+        converged = max_iter_reached = false;
+        push(T);
+    }
+    void push(const float* T) {
+        float q[4];
+        rot_to_quat(T, q);
+        quats.insert(quats.end(), q, q + 4);
+        trans.push_back(T[3]);
+        trans.push_back(T[7]);
+        trans.push_back(T[11]);
+    }
+    // returns `iterate`
+    bool check(const float* T) {
+        bool iterate = true;
+        push(T);
+        const int hist = (int)trans.size() / 3;
+        if (smooth_len > 0 && hist > smooth_len) {
+            float cr = 0.f, ct = 0.f;
+            for (int i = hist - 1; i >= hist - smooth_len; --i) {
+                cr += std::fabs(quat_angular_distance(&quats[4 * i], &quats[4 * (i - 1)]));
+                const float dx = trans[3 * i] - trans[3 * (i - 1)], dy = trans[3 * i + 1] - trans[3 * (i - 1) + 1],
+                            dz = trans[3 * i + 2] - trans[3 * (i - 1) + 2];
+                ct += std::sqrt(dx * dx + dy * dy + dz * dz);
+            }
+            cr /= (float)smooth_len;
+            ct /= (float)smooth_len;
+            if (cr < min_diff_rot && ct < min_diff_trans) {
+                iterate = false;
+                converged = true;
+            }
+        }
+        ++count;
+        if (count >= max_iter) {
+            iterate = false;
+            max_iter_reached = true;
+        }
+        return iterate;
+    }
+};
+
+}  // namespace o3dreg

@@ -1,0 +1,1493 @@
+// reg_core.hip -- C ABI (include/o3dslam_reg.h) + HIP kernels of the MI355X registration path.
+// gfx950 only.  The product never falls back to a CPU path: every entry point that needs the
+// device returns REG_DEVICE_ERROR when HIP fails.
+#include "../../include/o3dslam_reg.h"
+#include "host_math.hpp"
+#include "reg_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+using namespace o3dreg;
+
+// =================================================================================================
+// kernels: target preparation (R1)
+// =================================================================================================
+
+// Order-independent centroid: integer sum of llrint(x * 2^16) (numeric contract NC1).
+__global__ void k_centroid_sums(const float* __restrict__ xyz, int64_t stride, int64_t n, unsigned long long* sums) {
+    __shared__ long long sh[3][4];
+    long long s0 = 0, s1 = 0, s2 = 0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float* p = xyz + i * stride;
+        s0 += llrint((double)p[0] * 65536.0);
+        s1 += llrint((double)p[1] * 65536.0);
+        s2 += llrint((double)p[2] * 65536.0);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        s0 += __shfl_down(s0, o);
+        s1 += __shfl_down(s1, o);
+        s2 += __shfl_down(s2, o);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+        sh[0][wave] = s0;
+        sh[1][wave] = s1;
+        sh[2][wave] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        long long t = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[threadIdx.x][w];
+        atomicAdd(&sums[threadIdx.x], (unsigned long long)t);
+    }
+}
+
+__device__ __forceinline__ int f2ord(float f) {
+    int i = __float_as_int(f);
+    return i >= 0 ? i : i ^ 0x7fffffff;
+}
+__host__ __device__ __forceinline__ float ord2f(int i) {
+    int j = i >= 0 ? i : i ^ 0x7fffffff;
+    float f;
+    memcpy(&f, &j, 4);
+    return f;
+}
+
+// centred = fl(x - c); bounding box of the centred cloud (ordered-int atomics).
+__global__ void k_center_bbox(const float* __restrict__ xyz, int64_t stride, int64_t n, float cx, float cy, float cz,
+                              float4* __restrict__ out, int* bbox /* min xyz, max xyz as ordered ints */) {
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float* p = xyz + i * stride;
+        float4 q;
+        q.x = p[0] - cx;
+        q.y = p[1] - cy;
+        q.z = p[2] - cz;
+        q.w = __uint_as_float((uint32_t)i);
+        out[i] = q;
+        mn[0] = fminf(mn[0], q.x); mx[0] = fmaxf(mx[0], q.x);
+        mn[1] = fminf(mn[1], q.y); mx[1] = fmaxf(mx[1], q.y);
+        mn[2] = fminf(mn[2], q.z); mx[2] = fmaxf(mx[2], q.z);
+    }
+    for (int o = 32; o > 0; o >>= 1)
+        for (int k = 0; k < 3; ++k) {
+            mn[k] = fminf(mn[k], __shfl_down(mn[k], o));
+            mx[k] = fmaxf(mx[k], __shfl_down(mx[k], o));
+        }
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 3; ++k) {
+            atomicMin(&bbox[k], f2ord(mn[k]));
+            atomicMax(&bbox[3 + k], f2ord(mx[k]));
+        }
+}
+
+// sort key = (brick z,y,x | bin-in-brick z,y,x)
+__global__ void k_point_keys(const float4* __restrict__ pts, int64_t n, float ox, float oy, float oz, float inv_c,
+                             uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pts[i];
+    const int cx = (int)bin_coord_f(p.x, ox, inv_c);
+    const int cy = (int)bin_coord_f(p.y, oy, inv_c);
+    const int cz = (int)bin_coord_f(p.z, oz, inv_c);
+    const uint64_t bk = brick_key((uint32_t)(cx >> kBrickLog2), (uint32_t)(cy >> kBrickLog2), (uint32_t)(cz >> kBrickLog2));
+    const uint32_t local = ((cz & (kBrickDim - 1)) << (2 * kBrickLog2)) | ((cy & (kBrickDim - 1)) << kBrickLog2) |
+                           (cx & (kBrickDim - 1));
+    keys[i] = (bk << (3 * kBrickLog2)) | local;
+    vals[i] = (uint32_t)i;
+}
+
+__global__ void k_gather_target(const float4* __restrict__ centred, const uint32_t* __restrict__ order, int64_t n,
+                                const float* __restrict__ nrm, int64_t nrm_stride, const float* __restrict__ cov,
+                                float4* __restrict__ pts_sorted, float4* __restrict__ nrm_sorted,
+                                float4* __restrict__ cov_sorted /* 2 float4 per point */) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t src = order[i];
+    pts_sorted[i] = centred[src];
+    if (nrm_sorted) {
+        const float* q = nrm + (int64_t)src * nrm_stride;
+        nrm_sorted[i] = make_float4(q[0], q[1], q[2], 0.f);
+    }
+    if (cov_sorted) {
+        const float* q = cov + (int64_t)src * 6;
+        cov_sorted[2 * i] = make_float4(q[0], q[1], q[2], q[3]);
+        cov_sorted[2 * i + 1] = make_float4(q[4], q[5], 0.f, 0.f);
+    }
+}
+
+__global__ void k_brick_heads(const uint64_t* __restrict__ keys, int64_t n, uint32_t* __restrict__ flags) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    flags[i] = (i == 0 || (keys[i] >> (3 * kBrickLog2)) != (keys[i - 1] >> (3 * kBrickLog2))) ? 1u : 0u;
+}
+
+// brick_id = inclusive_scan(flags) - 1.  Inserts brick heads into the hash and counts points per bin.
+__global__ void k_fill_tables(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ flags,
+                              const uint32_t* __restrict__ scan, int64_t n, HashEntry* hash, uint32_t mask,
+                              uint32_t* __restrict__ counts, uint32_t* __restrict__ occupied) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t bid = scan[i] - 1u;
+    const uint64_t key = keys[i];
+    const uint32_t local = (uint32_t)(key & (kBrickCells - 1));
+    if (flags[i]) {
+        const uint64_t bk = key >> (3 * kBrickLog2);
+        uint32_t h = (uint32_t)mix64(bk) & mask;
+        for (;;) {
+            const unsigned long long prev =
+                atomicCAS((unsigned long long*)&hash[h].key, (unsigned long long)kEmptyKey, (unsigned long long)bk);
+            if (prev == kEmptyKey) {
+                hash[h].val = bid;
+                break;
+            }
+            h = (h + 1) & mask;
+        }
+    }
+    const uint32_t old = atomicAdd(&counts[(size_t)bid * kBrickCells + local], 1u);
+    if (old == 0) atomicAdd(occupied, 1u);
+}
+
+// =================================================================================================
+// kernels: reading preparation (R2)
+// =================================================================================================
+
+// reading' = T0 * (p - c_read), normals' = R0 * n  (ICP.cpp:966-984)
+__global__ void k_prepare_source(const float* __restrict__ xyz, int64_t stride, const float* __restrict__ nrm,
+                                 int64_t nrm_stride, int64_t n, float cx, float cy, float cz, Xf T0, int centre,
+                                 float4* __restrict__ out_xyz, float4* __restrict__ out_nrm) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* p = xyz + i * stride;
+    float x = p[0], y = p[1], z = p[2];
+    if (centre) {
+        x = x - cx;
+        y = y - cy;
+        z = z - cz;
+        const float3 q = xf_point(T0, x, y, z);
+        x = q.x; y = q.y; z = q.z;
+    }
+    out_xyz[i] = make_float4(x, y, z, 1.f);
+    if (out_nrm) {
+        const float* q = nrm + i * nrm_stride;
+        float3 r = make_float3(q[0], q[1], q[2]);
+        if (centre) r = xf_rot(T0, r.x, r.y, r.z);
+        out_nrm[i] = make_float4(r.x, r.y, r.z, 0.f);
+    }
+}
+
+__global__ void k_pack_cov(const float* __restrict__ cov, int64_t n, float4* __restrict__ out) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* q = cov + i * 6;
+    out[2 * i] = make_float4(q[0], q[1], q[2], q[3]);
+    out[2 * i + 1] = make_float4(q[4], q[5], 0.f, 0.f);
+}
+
+// =================================================================================================
+// kernels: the iteration (R3-R7)
+// =================================================================================================
+
+// R3 + R4: transform the reading by T_iter, exact 1-NN through the voxel-bin table.
+// Writes the sorted position of the match (-1 = none) and the squared distance (+inf = none), and the
+// level-0 radix histogram (top 11 bits) of the finite distances for the trimmed-quantile select.
+__global__ void __launch_bounds__(256)
+k_match(const float4* __restrict__ src, int64_t n, Xf T, Grid g, int* __restrict__ pos, float* __restrict__ d2,
+        uint32_t* __restrict__ hist0 /* 2048 or null */) {
+    __shared__ uint32_t sh[2048];
+    if (hist0) {
+        for (int k = threadIdx.x; k < 2048; k += blockDim.x) sh[k] = 0;
+        __syncthreads();
+    }
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float4 s = src[i];
+        const float3 p = xf_point(T, s.x, s.y, s.z);
+        const Best b = nearest(g, p);
+        pos[i] = b.pos;
+        d2[i] = b.pos >= 0 ? b.d2 : INFINITY;
+        if (hist0 && b.pos >= 0) atomicAdd(&sh[__float_as_uint(b.d2) >> 21], 1u);
+    }
+    if (hist0) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < 2048; k += blockDim.x)
+            if (sh[k]) atomicAdd(&hist0[k], sh[k]);
+    }
+}
+
+// Radix-select state kept on the device between the passes of one iteration.
+struct SelectState {
+    uint32_t prefix;     // bits of the k-th smallest value fixed so far (left-aligned)
+    uint32_t rank;       // remaining 0-based rank inside the selected bucket
+    uint32_t n_finite;
+    uint32_t done;
+    float limit;         // result: k-th smallest finite d2 (or max when ratio == 1)
+    uint32_t pad[3];
+};
+
+// level 0: bits [31:21], level 1: [20:10], level 2: [9:0]
+__global__ void k_select_pick(const uint32_t* __restrict__ hist, int level, float ratio, SelectState* st) {
+    __shared__ uint32_t sh[2048];
+    __shared__ uint32_t wave_tot[4];
+    const int nb = level == 2 ? 1024 : 2048;
+    // 256 threads, 8 bins each
+    uint32_t loc[8];
+    uint32_t sum = 0;
+    for (int k = 0; k < 8; ++k) {
+        const int b = threadIdx.x * 8 + k;
+        loc[k] = b < nb ? hist[b] : 0u;
+        sum += loc[k];
+    }
+    // block exclusive scan of per-thread sums
+    uint32_t incl = sum;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; ++w) base += wave_tot[w];
+    uint32_t excl = base + incl - sum;
+    __shared__ uint32_t s_rank, s_total;
+    if (threadIdx.x == 0) {
+        const uint32_t total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        s_total = total;
+        if (level == 0) {
+            st->n_finite = total;
+            uint32_t r;
+            if (ratio == 1.0f) {
+                r = total ? total - 1 : 0;
+            } else {
+                // `values.size() * quantile` evaluated in float, truncated (Matches.cpp:85-86)
+                const float posf = (float)total * ratio;
+                r = (uint32_t)posf;
+                if (total && r >= total) r = total - 1;
+            }
+            s_rank = r;
+        } else {
+            s_rank = st->rank;
+        }
+    }
+    (void)sh;
+    __syncthreads();
+    const uint32_t rank = s_rank;
+    if (s_total == 0) {
+        if (threadIdx.x == 0) {
+            st->limit = INFINITY;
+            st->done = 1;
+        }
+        return;
+    }
+    // the bin whose [excl, excl+count) range contains `rank`
+    uint32_t run = excl;
+    for (int k = 0; k < 8; ++k) {
+        const int b = threadIdx.x * 8 + k;
+        if (b < nb && loc[k] && rank >= run && rank < run + loc[k]) {
+            const uint32_t shift = level == 0 ? 21 : (level == 1 ? 10 : 0);
+            const uint32_t prefix = (level == 0 ? 0u : st->prefix) | ((uint32_t)b << shift);
+            st->prefix = prefix;
+            st->rank = rank - run;
+            if (level == 2) {
+                st->limit = __uint_as_float(prefix);
+                st->done = 1;
+            }
+        }
+        run += loc[k];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_select_hist(const float* __restrict__ d2, int64_t n, int level, const SelectState* __restrict__ st,
+              uint32_t* __restrict__ hist) {
+    __shared__ uint32_t sh[2048];
+    for (int k = threadIdx.x; k < 2048; k += blockDim.x) sh[k] = 0;
+    __syncthreads();
+    const uint32_t prefix = st->prefix;
+    const uint32_t mask = level == 1 ? 0xffe00000u : 0xfffffc00u;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t u = __float_as_uint(d2[i]);
+        if (u != 0x7f800000u && (u & mask) == prefix) {
+            const uint32_t b = level == 1 ? ((u >> 10) & 2047u) : (u & 1023u);
+            atomicAdd(&sh[b], 1u);
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 2048; k += blockDim.x)
+        if (sh[k]) atomicAdd(&hist[k], sh[k]);
+}
+
+struct FilterCfg {
+    int use_trim, use_normal, use_maxdist;
+    float cos_max_angle;
+    float outlier_max_d2;
+};
+
+__device__ __forceinline__ float3 normalize3(float3 n) {
+    float a = n.x * n.x;
+    float b = n.y * n.y;
+    float z = a + b;
+    a = n.z * n.z;
+    z = z + a;
+    if (z > 0.f) {
+        const float s = sqrtf(z);
+        n.x = n.x / s;
+        n.y = n.y / s;
+        n.z = n.z / s;
+    }
+    return n;
+}
+
+// wave-level sum of a double over 64 lanes
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    return v;
+}
+
+// block partial -> global: partials[blockIdx.x][kSums]
+__device__ __forceinline__ void block_reduce_store(double* vals /* kSums per thread */, double* __restrict__ partials) {
+    __shared__ double sh[4][kSums];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < kSums; ++k) {
+        const double s = wave_sum(vals[k]);
+        if (lane == 0) sh[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < kSums) {
+        double t = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[w][threadIdx.x];
+        partials[(size_t)blockIdx.x * kSums + threadIdx.x] = t;
+    }
+}
+
+// R5 + R6 + R7 (point-to-plane): weights, F = [p x n ; n], A += w F F^T, b -= w F (n.(p-q)).
+// Per-pair products in fp32 (as the reference computes them), summed in fp64 (numeric contract NC8).
+__global__ void __launch_bounds__(256)
+k_linearize_p2pl(const float4* __restrict__ src, const float4* __restrict__ src_nrm, int64_t n, Xf T,
+                 const int* __restrict__ pos, const float* __restrict__ d2, const float4* __restrict__ tgt,
+                 const float4* __restrict__ tgt_nrm, FilterCfg f, const SelectState* __restrict__ st,
+                 float* __restrict__ w_out, double* __restrict__ partials) {
+    double v[kSums];
+#pragma unroll
+    for (int k = 0; k < kSums; ++k) v[k] = 0.0;
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) {
+        const int ps = pos[i];
+        const float dd = d2[i];
+        float w = 0.f;
+        if (ps >= 0) {
+            v[29] = 1.0;
+            w = 1.f;
+            if (f.use_maxdist && !(dd <= f.outlier_max_d2)) w = 0.f;
+            if (f.use_trim && !(dd <= st->limit)) w = 0.f;
+            const float4 s = src[i];
+            const float3 p = xf_point(T, s.x, s.y, s.z);
+            const float4 nn = tgt_nrm[ps];
+            if (f.use_normal) {
+                const float4 sn = src_nrm[i];
+                const float3 nr = normalize3(xf_rot(T, sn.x, sn.y, sn.z));
+                const float3 nt = normalize3(make_float3(nn.x, nn.y, nn.z));
+                float a = nr.x * nt.x;
+                float b = nr.y * nt.y;
+                float val = a + b;
+                a = nr.z * nt.z;
+                val = val + a;
+                if (val < f.cos_max_angle) w = 0.f;
+            }
+            if (w != 0.f) {
+                const float4 q = tgt[ps];
+                float F[6];
+                float a = p.y * nn.z, b = p.z * nn.y;
+                F[0] = a - b;
+                a = p.z * nn.x; b = p.x * nn.z;
+                F[1] = a - b;
+                a = p.x * nn.y; b = p.y * nn.x;
+                F[2] = a - b;
+                F[3] = nn.x; F[4] = nn.y; F[5] = nn.z;
+                const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
+                float r = dx * nn.x;
+                float t2 = dy * nn.y;
+                r = r + t2;
+                t2 = dz * nn.z;
+                r = r + t2;
+                int k = 0;
+#pragma unroll
+                for (int a6 = 0; a6 < 6; ++a6) {
+                    const float wf = w * F[a6];
+#pragma unroll
+                    for (int c6 = a6; c6 < 6; ++c6) {
+                        const float pr = wf * F[c6];
+                        v[k++] = (double)pr;
+                    }
+                }
+#pragma unroll
+                for (int a6 = 0; a6 < 6; ++a6) {
+                    const float wf = w * F[a6];
+                    const float pr = wf * r;
+                    v[21 + a6] = (double)pr;
+                }
+                const float rr = r * r;
+                v[27] = (double)(w * rr);
+                v[28] = 1.0;
+                v[30] = (double)dd;
+            }
+        }
+        if (w_out) w_out[i] = w;
+    }
+    block_reduce_store(v, partials);
+}
+
+// GICP factor (north-star cost): r = q - T p, M = (Cq + R Cp R^T)^-1, J = [R skew(p), -R];
+// H += J^T M J, b += J^T M r, e += 0.5 r^T M r.  Per-point algebra in fp64 (inputs fp32).
+__global__ void __launch_bounds__(256)
+k_linearize_gicp(const float4* __restrict__ src, const float4* __restrict__ src_cov, int64_t n, Xf T,
+                 const int* __restrict__ pos, const float* __restrict__ d2, const float4* __restrict__ tgt,
+                 const float4* __restrict__ tgt_cov, float* __restrict__ w_out, double* __restrict__ partials) {
+    double v[kSums];
+#pragma unroll
+    for (int k = 0; k < kSums; ++k) v[k] = 0.0;
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) {
+        const int ps = pos[i];
+        float w = 0.f;
+        if (ps >= 0) {
+            w = 1.f;
+            const float4 s = src[i];
+            const float3 tp = xf_point(T, s.x, s.y, s.z);
+            const float4 q = tgt[ps];
+            const double r[3] = {(double)q.x - (double)tp.x, (double)q.y - (double)tp.y, (double)q.z - (double)tp.z};
+            const float4 a0 = src_cov[2 * i], a1 = src_cov[2 * i + 1];
+            const float4 b0 = tgt_cov[2 * (int64_t)ps], b1 = tgt_cov[2 * (int64_t)ps + 1];
+            const double Cp[9] = {a0.x, a0.y, a0.z, a0.y, a0.w, a1.x, a0.z, a1.x, a1.y};
+            const double Cq[9] = {b0.x, b0.y, b0.z, b0.y, b0.w, b1.x, b0.z, b1.x, b1.y};
+            double R[9];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) R[3 * a + c] = (double)T.m[4 * a + c];
+            double RC[9], S[9];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    double t = 0;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) t += R[3 * a + k] * Cp[3 * k + c];
+                    RC[3 * a + c] = t;
+                }
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    double t = 0;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) t += RC[3 * a + k] * R[3 * c + k];
+                    S[3 * a + c] = t + Cq[3 * a + c];
+                }
+            // symmetric 3x3 inverse
+            double Mi[9];
+            {
+                const double a = S[0], b = S[1], c = S[2], d = S[4], e = S[5], ff = S[8];
+                const double co00 = d * ff - e * e, co01 = c * e - b * ff, co02 = b * e - c * d;
+                const double id = 1.0 / (a * co00 + b * co01 + c * co02);
+                Mi[0] = co00 * id;
+                Mi[1] = Mi[3] = co01 * id;
+                Mi[2] = Mi[6] = co02 * id;
+                Mi[4] = (a * ff - c * c) * id;
+                Mi[5] = Mi[7] = (b * c - a * e) * id;
+                Mi[8] = (a * d - b * b) * id;
+            }
+            const double px = s.x, py = s.y, pz = s.z;
+            const double sk[9] = {0, -pz, py, pz, 0, -px, -py, px, 0};
+            double J[18];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    double t = 0;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) t += R[3 * a + k] * sk[3 * k + c];
+                    J[6 * a + c] = t;
+                    J[6 * a + 3 + c] = -R[3 * a + c];
+                }
+            double MJ[18], Mr[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    double t = 0;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) t += Mi[3 * a + k] * J[6 * k + c];
+                    MJ[6 * a + c] = t;
+                }
+                Mr[a] = Mi[3 * a] * r[0] + Mi[3 * a + 1] * r[1] + Mi[3 * a + 2] * r[2];
+            }
+            int k = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int c = a; c < 6; ++c) {
+                    double t = 0;
+#pragma unroll
+                    for (int kk = 0; kk < 3; ++kk) t += J[6 * kk + a] * MJ[6 * kk + c];
+                    v[k++] = t;
+                }
+#pragma unroll
+            for (int a = 0; a < 6; ++a) v[21 + a] = J[a] * Mr[0] + J[6 + a] * Mr[1] + J[12 + a] * Mr[2];
+            v[27] = 0.5 * (r[0] * Mr[0] + r[1] * Mr[1] + r[2] * Mr[2]);
+            v[28] = 1.0;
+            v[29] = 1.0;
+            v[30] = (double)d2[i];
+        }
+        if (w_out) w_out[i] = w;
+    }
+    block_reduce_store(v, partials);
+}
+
+// fixed-order sum of the block partials -> out[kSums]
+__global__ void k_final_reduce(const double* __restrict__ partials, int n_blocks, double* __restrict__ out) {
+    __shared__ double sh[8][kSums];
+    const int comp = threadIdx.x & (kSums - 1), part = threadIdx.x / kSums;  // 256 threads = 8 parts x 32 comps
+    double t = 0;
+    for (int b = part; b < n_blocks; b += 8) t += partials[(size_t)b * kSums + comp];
+    sh[part][comp] = t;
+    __syncthreads();
+    if (threadIdx.x < kSums) {
+        double s = 0;
+        for (int p = 0; p < 8; ++p) s += sh[p][threadIdx.x];
+        out[threadIdx.x] = s;
+    }
+}
+
+__global__ void k_ids_from_pos(const int* __restrict__ pos, const float4* __restrict__ tgt, int64_t n, int32_t* ids) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int p = pos[i];
+    ids[i] = p >= 0 ? (int32_t)__float_as_uint(tgt[p].w) : -1;
+}
+
+// =================================================================================================
+// host side
+// =================================================================================================
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T* as() const {
+        return (T*)p;
+    }
+};
+
+struct reg_handle {
+    reg_params prm;
+    std::string err;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    // target
+    int64_t m = 0;
+    bool has_tnrm = false, has_tcov = false;
+    float c_ref[3] = {0, 0, 0};
+    DevBuf t_raw, t_nrm_raw, t_cov_raw, t_centred, t_keys, t_keys2, t_vals, t_vals2, t_pts, t_nrm, t_cov, t_flags,
+        t_scan, t_hash, t_cells, t_tmp, t_misc;
+    Grid grid;
+    reg_target_info info;
+    float target_build_ms = 0.f;
+
+    // source
+    int64_t n = 0;
+    bool has_snrm = false, has_scov = false, prepared = false;
+    int64_t s_stride = 3, s_nstride = 3;
+    float c_read[3] = {0, 0, 0};
+    DevBuf s_raw, s_nrm_raw, s_cov_raw, s_xyz, s_nrm, s_cov, s_misc;
+    float T_init[16];              // row-major
+    float T0[16];                  // T_refMean_readMean (row-major)
+    // iteration buffers
+    DevBuf i_pos, i_d2, i_w, i_hist, i_state, i_partials, i_sums, i_ids;
+    double* h_sums = nullptr;      // pinned
+    int n_blocks = 0;
+    bool have_match = false;
+};
+
+#define HIPCHK(h, call)                                                                        \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                      \
+            return REG_DEVICE_ERROR;                                                           \
+        }                                                                                      \
+    } while (0)
+
+static inline void col_to_row(const float* c, float* r) { m4_transpose(c, r); }
+static inline void row_to_col(const float* r, float* c) { m4_transpose(r, c); }
+
+static Xf make_xf(const float* T_row) {
+    Xf x;
+    std::memcpy(x.m, T_row, 12 * sizeof(float));
+    return x;
+}
+
+static inline int grid_for(int64_t n, int block = 256) { return (int)((n + block - 1) / block); }
+
+extern "C" {
+
+void reg_default_params(reg_params* p) {
+    std::memset(p, 0, sizeof(*p));
+    p->struct_size = (int32_t)sizeof(reg_params);
+    p->cost = REG_COST_P2PL;
+    p->knn = 1;
+    p->max_dist = std::numeric_limits<float>::infinity();
+    p->epsilon = 0.f;
+    p->use_trimmed = 1;
+    p->trim_ratio = 0.85f;
+    p->use_surface_normal = 0;
+    p->max_normal_angle = 1.57f;
+    p->use_max_dist_filter = 0;
+    p->outlier_max_dist = 1.f;
+    p->max_iter = 40;
+    p->min_diff_rot = 0.001f;
+    p->min_diff_trans = 0.001f;
+    p->smooth_len = 3;
+    p->fixed_iters = 0;
+    p->gicp_rot_eps = 0.1f * 3.14159265358979f / 180.f;
+    p->gicp_trans_eps = 1e-3f;
+    p->cell_size = 0.f;
+    p->device = 0;
+    p->sort_source = 0;
+}
+
+void reg_shipped_params(reg_params* p) {
+    reg_default_params(p);
+    p->max_dist = 0.5f;
+    p->epsilon = 0.f;
+    p->use_trimmed = 1;
+    p->trim_ratio = 0.90f;
+    p->use_surface_normal = 1;
+    p->max_normal_angle = 1.57f;
+    p->max_iter = 30;
+    p->min_diff_rot = 0.001f;
+    p->min_diff_trans = 0.008f;
+    p->smooth_len = 3;
+}
+
+reg_status reg_create(const reg_params* p, reg_handle** out) {
+    if (!p || !out) return REG_BAD_ARGUMENT;
+    *out = nullptr;
+    if (p->struct_size != (int32_t)sizeof(reg_params)) return REG_BAD_ARGUMENT;
+    if (p->knn != 1) return REG_BAD_ARGUMENT;
+    if (!(p->max_dist > 0.f)) return REG_BAD_ARGUMENT;
+    if (p->cost != REG_COST_P2PL && p->cost != REG_COST_GICP) return REG_BAD_ARGUMENT;
+    if (p->use_trimmed && !(p->trim_ratio >= 0.f && p->trim_ratio <= 1.f)) return REG_BAD_ARGUMENT;
+    if (p->fixed_iters <= 0 && p->max_iter <= 0) return REG_BAD_ARGUMENT;
+    reg_handle* h = new reg_handle();
+    h->prm = *p;
+    std::memset(&h->info, 0, sizeof(h->info));
+    std::memset(&h->grid, 0, sizeof(h->grid));
+    if (hipSetDevice(p->device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        // keep the handle so that reg_last_error can explain; entry points will fail loudly
+        h->err = "no usable HIP device (hipSetDevice/hipStreamCreate failed): the HIP path is mandatory";
+        h->stream = nullptr;
+        *out = h;
+        return REG_DEVICE_ERROR;
+    }
+    h->own_stream = true;
+    (void)hipEventCreate(&h->ev0);
+    (void)hipEventCreate(&h->ev1);
+    (void)hipHostMalloc((void**)&h->h_sums, kSums * sizeof(double), hipHostMallocDefault);
+    *out = h;
+    return REG_OK;
+}
+
+void reg_destroy(reg_handle* h) {
+    if (!h) return;
+    DevBuf* bufs[] = {&h->t_raw, &h->t_nrm_raw, &h->t_cov_raw, &h->t_centred, &h->t_keys, &h->t_keys2, &h->t_vals,
+                      &h->t_vals2, &h->t_pts, &h->t_nrm, &h->t_cov, &h->t_flags, &h->t_scan, &h->t_hash, &h->t_cells,
+                      &h->t_tmp, &h->t_misc, &h->s_raw, &h->s_nrm_raw, &h->s_cov_raw, &h->s_xyz, &h->s_nrm, &h->s_cov,
+                      &h->s_misc, &h->i_pos, &h->i_d2, &h->i_w, &h->i_hist, &h->i_state, &h->i_partials, &h->i_sums,
+                      &h->i_ids};
+    for (DevBuf* b : bufs) b->release();
+    if (h->h_sums) (void)hipHostFree(h->h_sums);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+const char* reg_last_error(const reg_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+reg_status reg_set_stream(reg_handle* h, void* hip_stream) {
+    if (!h) return REG_BAD_ARGUMENT;
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    h->stream = (hipStream_t)hip_stream;
+    h->own_stream = false;
+    return REG_OK;
+}
+
+}  // extern "C"
+
+// copy (host or device) -> device buffer
+static reg_status upload(reg_handle* h, DevBuf& dst, const float* src, size_t bytes, int on_device) {
+    HIPCHK(h, dst.reserve(bytes));
+    HIPCHK(h, hipMemcpyAsync(dst.p, src, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+    return REG_OK;
+}
+
+static reg_status device_centroid(reg_handle* h, const float* d_xyz, int64_t stride, int64_t n, DevBuf& misc, float out[3]) {
+    HIPCHK(h, misc.reserve(256));
+    HIPCHK(h, hipMemsetAsync(misc.p, 0, 3 * sizeof(unsigned long long), h->stream));
+    const int blocks = std::min<int64_t>(1024, (n + 255) / 256);
+    k_centroid_sums<<<blocks, 256, 0, h->stream>>>(d_xyz, stride, n, misc.as<unsigned long long>());
+    long long s[3];
+    HIPCHK(h, hipMemcpyAsync(s, misc.p, sizeof(s), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int k = 0; k < 3; ++k) out[k] = (float)((double)s[k] / (65536.0 * (double)n));
+    return REG_OK;
+}
+
+// Build the brick table for bin edge c.  Returns occupied-bin count through *occupied.
+static reg_status build_grid(reg_handle* h, float c, const float bmin[3], const float bmax[3], uint32_t* occupied) {
+    const int64_t m = h->m;
+    Grid& g = h->grid;
+    const float inv_c = 1.0f / c;
+    g.ox = bmin[0];
+    g.oy = bmin[1];
+    g.oz = bmin[2];
+    g.inv_c = inv_c;
+    float dims[3];
+    for (int k = 0; k < 3; ++k) {
+        volatile float d = bmax[k] - bmin[k];
+        volatile float s = d * inv_c;
+        dims[k] = std::floor((float)s) + 1.0f;
+    }
+    const double max_dim = (double)(1u << (kBrickBits + kBrickLog2));
+    if (dims[0] > max_dim || dims[1] > max_dim || dims[2] > max_dim) {
+        h->err = "cell_size too small for the target extent (bin coordinates overflow the sort key)";
+        return REG_BAD_ARGUMENT;
+    }
+    g.dimx = dims[0];
+    g.dimy = dims[1];
+    g.dimz = dims[2];
+    h->info.dims[0] = (int32_t)dims[0];
+    h->info.dims[1] = (int32_t)dims[1];
+    h->info.dims[2] = (int32_t)dims[2];
+
+    HIPCHK(h, h->t_keys.reserve(m * 8));
+    HIPCHK(h, h->t_keys2.reserve(m * 8));
+    HIPCHK(h, h->t_vals.reserve(m * 4));
+    HIPCHK(h, h->t_vals2.reserve(m * 4));
+    k_point_keys<<<grid_for(m), 256, 0, h->stream>>>(h->t_centred.as<float4>(), m, g.ox, g.oy, g.oz, inv_c,
+                                                      h->t_keys.as<uint64_t>(), h->t_vals.as<uint32_t>());
+    // significant key bits
+    auto bits_for = [](double v) { int b = 1; while ((double)(1ull << b) < v) ++b; return b; };
+    const int bz_bits = bits_for(std::ceil(dims[2] / kBrickDim) + 1);
+    const int end_bit = std::min(64, 3 * kBrickLog2 + 2 * kBrickBits + bz_bits);
+    size_t tmp_bytes = 0;
+    HIPCHK(h, rocprim::radix_sort_pairs(nullptr, tmp_bytes, h->t_keys.as<uint64_t>(), h->t_keys2.as<uint64_t>(),
+                                        h->t_vals.as<uint32_t>(), h->t_vals2.as<uint32_t>(), (size_t)m, 0, end_bit,
+                                        h->stream));
+    HIPCHK(h, h->t_tmp.reserve(tmp_bytes));
+    HIPCHK(h, rocprim::radix_sort_pairs(h->t_tmp.p, tmp_bytes, h->t_keys.as<uint64_t>(), h->t_keys2.as<uint64_t>(),
+                                        h->t_vals.as<uint32_t>(), h->t_vals2.as<uint32_t>(), (size_t)m, 0, end_bit,
+                                        h->stream));
+    // brick heads -> brick ids
+    HIPCHK(h, h->t_flags.reserve(m * 4));
+    HIPCHK(h, h->t_scan.reserve(m * 4));
+    k_brick_heads<<<grid_for(m), 256, 0, h->stream>>>(h->t_keys2.as<uint64_t>(), m, h->t_flags.as<uint32_t>());
+    size_t scan_bytes = 0;
+    HIPCHK(h, rocprim::inclusive_scan(nullptr, scan_bytes, h->t_flags.as<uint32_t>(), h->t_scan.as<uint32_t>(),
+                                      (size_t)m, rocprim::plus<uint32_t>(), h->stream));
+    HIPCHK(h, h->t_tmp.reserve(scan_bytes));
+    HIPCHK(h, rocprim::inclusive_scan(h->t_tmp.p, scan_bytes, h->t_flags.as<uint32_t>(), h->t_scan.as<uint32_t>(),
+                                      (size_t)m, rocprim::plus<uint32_t>(), h->stream));
+    uint32_t nb = 0;
+    HIPCHK(h, hipMemcpyAsync(&nb, h->t_scan.as<uint32_t>() + (m - 1), 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    // tables
+    uint32_t cap = 16;
+    while (cap < 2 * nb) cap <<= 1;
+    HIPCHK(h, h->t_hash.reserve((size_t)cap * sizeof(HashEntry)));
+    HIPCHK(h, hipMemsetAsync(h->t_hash.p, 0xff, (size_t)cap * sizeof(HashEntry), h->stream));
+    const size_t n_cells = (size_t)nb * kBrickCells + 1;
+    HIPCHK(h, h->t_cells.reserve(n_cells * 4));
+    HIPCHK(h, hipMemsetAsync(h->t_cells.p, 0, n_cells * 4, h->stream));
+    HIPCHK(h, h->t_misc.reserve(256));
+    HIPCHK(h, hipMemsetAsync(h->t_misc.p, 0, 64, h->stream));
+    k_fill_tables<<<grid_for(m), 256, 0, h->stream>>>(h->t_keys2.as<uint64_t>(), h->t_flags.as<uint32_t>(),
+                                                       h->t_scan.as<uint32_t>(), m, h->t_hash.as<HashEntry>(), cap - 1,
+                                                       h->t_cells.as<uint32_t>(), h->t_misc.as<uint32_t>());
+    size_t ex_bytes = 0;
+    HIPCHK(h, rocprim::exclusive_scan(nullptr, ex_bytes, h->t_cells.as<uint32_t>(), h->t_cells.as<uint32_t>(), 0u,
+                                      n_cells, rocprim::plus<uint32_t>(), h->stream));
+    HIPCHK(h, h->t_tmp.reserve(ex_bytes));
+    HIPCHK(h, rocprim::exclusive_scan(h->t_tmp.p, ex_bytes, h->t_cells.as<uint32_t>(), h->t_cells.as<uint32_t>(), 0u,
+                                      n_cells, rocprim::plus<uint32_t>(), h->stream));
+    HIPCHK(h, hipMemcpyAsync(occupied, h->t_misc.p, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    g.hash_mask = cap - 1;
+    g.hash = h->t_hash.as<HashEntry>();
+    g.cell_start = h->t_cells.as<uint32_t>();
+    h->info.n_bricks = nb;
+    h->info.n_cells_occupied = *occupied;
+    h->info.table_bytes = (int64_t)((size_t)cap * sizeof(HashEntry) + n_cells * 4);
+    h->info.cell_size = c;
+    return REG_OK;
+}
+
+static void set_levels(reg_handle* h, float c, float max_abs) {
+    Grid& g = h->grid;
+    const float md = h->prm.max_dist;
+    g.max_d2 = std::isinf(md) ? INFINITY : md * md;
+    int n = 0;
+    float rho = 0.5f * c;
+    const float abs_margin = 4e-7f * (1.0f + max_abs);
+    while (n < kMaxLevels - 1 && rho < md) {
+        g.rho[n] = rho;
+        g.rho_box[n] = rho + 1e-3f * rho + abs_margin;
+        ++n;
+        rho *= 2.0f;
+        if (std::isinf(md) && n >= 6) break;  // unbounded search: after 6 doublings fall through to a full scan
+    }
+    g.rho[n] = md;
+    g.rho_box[n] = std::isinf(md) ? INFINITY : md + 1e-3f * md + abs_margin;
+    ++n;
+    g.n_levels = n;
+}
+
+extern "C" {
+
+reg_status reg_set_target(reg_handle* h, const float* xyz, int64_t xyz_stride, const float* nrm, int64_t nrm_stride,
+                          const float* cov, int64_t m, int on_device) {
+    if (!h) return REG_BAD_ARGUMENT;
+    if (!h->stream) return REG_DEVICE_ERROR;
+    h->m = 0;
+    h->have_match = false;
+    if (m <= 0) {
+        h->err = "The reference point cloud is empty";
+        return REG_EMPTY_TARGET;
+    }
+    if (!xyz || xyz_stride < 3 || (nrm && nrm_stride < 3) || m > 0x7fffffffLL) return REG_BAD_ARGUMENT;
+    if (h->prm.cost == REG_COST_P2PL && !nrm) {
+        h->err = "InvalidField: point-to-plane needs the `normals` descriptor on the reference";
+        return REG_MISSING_FIELD;
+    }
+    if (h->prm.cost == REG_COST_GICP && !cov) {
+        h->err = "InvalidField: GICP needs covariances on the reference";
+        return REG_MISSING_FIELD;
+    }
+    HIPCHK(h, hipSetDevice(h->prm.device));
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    const float* d_xyz = xyz;
+    const float* d_nrm = nrm;
+    const float* d_cov = cov;
+    if (!on_device) {
+        reg_status s = upload(h, h->t_raw, xyz, (size_t)m * xyz_stride * 4, 0);
+        if (s != REG_OK) return s;
+        d_xyz = h->t_raw.as<float>();
+        if (nrm) {
+            s = upload(h, h->t_nrm_raw, nrm, (size_t)m * nrm_stride * 4, 0);
+            if (s != REG_OK) return s;
+            d_nrm = h->t_nrm_raw.as<float>();
+        }
+        if (cov) {
+            s = upload(h, h->t_cov_raw, cov, (size_t)m * 6 * 4, 0);
+            if (s != REG_OK) return s;
+            d_cov = h->t_cov_raw.as<float>();
+        }
+    }
+    h->m = m;
+    h->has_tnrm = nrm != nullptr;
+    h->has_tcov = cov != nullptr;
+    // R1: centroid (P2PL path only: GICP works in the input frame, as small_gicp does)
+    float c[3] = {0, 0, 0};
+    if (h->prm.cost == REG_COST_P2PL) {
+        reg_status s = device_centroid(h, d_xyz, xyz_stride, m, h->t_misc, c);
+        if (s != REG_OK) return s;
+    }
+    std::memcpy(h->c_ref, c, sizeof(c));
+    std::memcpy(h->info.centroid, c, sizeof(c));
+    // centred copy + bbox
+    HIPCHK(h, h->t_centred.reserve((size_t)m * 16));
+    HIPCHK(h, h->t_misc.reserve(256));
+    int bb_init[6] = {0x7f800000, 0x7f800000, 0x7f800000, (int)0x80000000 ^ 0, 0, 0};
+    // ordered-int encodings of +inf / -inf
+    bb_init[0] = bb_init[1] = bb_init[2] = 0x7f800000;                    // +inf
+    bb_init[3] = bb_init[4] = bb_init[5] = (int)(0xff800000u ^ 0x7fffffffu);  // -inf
+    HIPCHK(h, hipMemcpyAsync(h->t_misc.p, bb_init, sizeof(bb_init), hipMemcpyHostToDevice, h->stream));
+    const int blocks = (int)std::min<int64_t>(2048, (m + 255) / 256);
+    k_center_bbox<<<blocks, 256, 0, h->stream>>>(d_xyz, xyz_stride, m, c[0], c[1], c[2], h->t_centred.as<float4>(),
+                                                 h->t_misc.as<int>());
+    int bb[6];
+    HIPCHK(h, hipMemcpyAsync(bb, h->t_misc.p, sizeof(bb), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float bmin[3], bmax[3], max_abs = 0.f;
+    for (int k = 0; k < 3; ++k) {
+        bmin[k] = ord2f(bb[k]);
+        bmax[k] = ord2f(bb[3 + k]);
+        if (!std::isfinite(bmin[k]) || !std::isfinite(bmax[k])) {
+            h->err = "reference cloud contains non-finite coordinates";
+            h->m = 0;
+            return REG_BAD_ARGUMENT;
+        }
+        max_abs = std::max(max_abs, std::max(std::fabs(bmin[k]), std::fabs(bmax[k])));
+    }
+    // bin edge: user value, or adapt to ~8 points per occupied bin (surface-like clouds: count ~ c^2)
+    float cs = h->prm.cell_size;
+    uint32_t occupied = 0;
+    if (cs > 0.f) {
+        reg_status s = build_grid(h, cs, bmin, bmax, &occupied);
+        if (s != REG_OK) return s;
+    } else {
+        const float ext = std::max(bmax[0] - bmin[0], std::max(bmax[1] - bmin[1], bmax[2] - bmin[2]));
+        // start from the edge that would give 8 points per bin if the cloud were a single ext x ext sheet
+        cs = std::max(ext * std::sqrt(8.0f / (float)m), 1e-4f * std::max(ext, 1e-3f));
+        const float cs_min = std::max(ext / (float)(1u << 20), 1e-6f);
+        cs = std::max(cs, cs_min);
+        for (int pass = 0; pass < 3; ++pass) {
+            reg_status s = build_grid(h, cs, bmin, bmax, &occupied);
+            if (s != REG_OK) return s;
+            const float per = (float)m / (float)std::max(1u, occupied);
+            if (per <= 12.0f && per >= 5.0f) break;
+            if (pass == 2) break;
+            float next = cs * std::sqrt(8.0f / per);
+            next = std::max(next, cs_min);
+            if (std::fabs(next - cs) < 0.05f * cs) break;
+            cs = next;
+        }
+    }
+    // sorted arrays
+    HIPCHK(h, h->t_pts.reserve((size_t)m * 16));
+    if (d_nrm) HIPCHK(h, h->t_nrm.reserve((size_t)m * 16));
+    if (d_cov) HIPCHK(h, h->t_cov.reserve((size_t)m * 32));
+    k_gather_target<<<grid_for(m), 256, 0, h->stream>>>(h->t_centred.as<float4>(), h->t_vals2.as<uint32_t>(), m, d_nrm,
+                                                         nrm_stride, d_cov, h->t_pts.as<float4>(),
+                                                         d_nrm ? h->t_nrm.as<float4>() : nullptr,
+                                                         d_cov ? h->t_cov.as<float4>() : nullptr);
+    h->grid.pts = h->t_pts.as<float4>();
+    set_levels(h, cs, max_abs);
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    (void)hipEventElapsedTime(&h->target_build_ms, h->ev0, h->ev1);
+    h->info.n_points = m;
+    h->info.origin[0] = bmin[0];
+    h->info.origin[1] = bmin[1];
+    h->info.origin[2] = bmin[2];
+    return REG_OK;
+}
+
+reg_status reg_get_target_info(const reg_handle* h, reg_target_info* info) {
+    if (!h || !info) return REG_BAD_ARGUMENT;
+    if (h->m == 0) return REG_NOT_CONFIGURED;
+    *info = h->info;
+    return REG_OK;
+}
+
+reg_status reg_set_source(reg_handle* h, const float* xyz, int64_t xyz_stride, const float* nrm, int64_t nrm_stride,
+                          const float* cov, int64_t n, int on_device) {
+    if (!h) return REG_BAD_ARGUMENT;
+    if (!h->stream) return REG_DEVICE_ERROR;
+    h->n = 0;
+    h->prepared = false;
+    h->have_match = false;
+    if (n <= 0) {
+        h->err = "The reading point cloud is empty.";
+        return REG_EMPTY_SOURCE;
+    }
+    if (!xyz || xyz_stride < 3 || (nrm && nrm_stride < 3) || n > 0x7fffffffLL) return REG_BAD_ARGUMENT;
+    if (h->prm.cost == REG_COST_P2PL && h->prm.use_surface_normal && !nrm) {
+        h->err = "InvalidField: SurfaceNormalOutlierFilter needs the `normals` descriptor on the reading";
+        return REG_MISSING_FIELD;
+    }
+    if (h->prm.cost == REG_COST_GICP && !cov) {
+        h->err = "InvalidField: GICP needs covariances on the reading";
+        return REG_MISSING_FIELD;
+    }
+    HIPCHK(h, hipSetDevice(h->prm.device));
+    // packed private copies (the reference deep-copies the reading, ICP.cpp:952)
+    reg_status s = upload(h, h->s_raw, xyz, (size_t)n * xyz_stride * 4, on_device);
+    if (s != REG_OK) return s;
+    if (nrm) {
+        s = upload(h, h->s_nrm_raw, nrm, (size_t)n * nrm_stride * 4, on_device);
+        if (s != REG_OK) return s;
+    }
+    if (cov) {
+        s = upload(h, h->s_cov_raw, cov, (size_t)n * 24, on_device);
+        if (s != REG_OK) return s;
+    }
+    h->n = n;
+    h->has_snrm = nrm != nullptr;
+    h->has_scov = cov != nullptr;
+    // iteration buffers
+    HIPCHK(h, h->s_xyz.reserve((size_t)n * 16));
+    if (nrm) HIPCHK(h, h->s_nrm.reserve((size_t)n * 16));
+    if (cov) HIPCHK(h, h->s_cov.reserve((size_t)n * 32));
+    HIPCHK(h, h->i_pos.reserve((size_t)n * 4));
+    HIPCHK(h, h->i_d2.reserve((size_t)n * 4));
+    HIPCHK(h, h->i_w.reserve((size_t)n * 4));
+    HIPCHK(h, h->i_hist.reserve(3 * 2048 * 4));
+    HIPCHK(h, h->i_state.reserve(sizeof(SelectState)));
+    h->n_blocks = grid_for(n);
+    HIPCHK(h, h->i_partials.reserve((size_t)h->n_blocks * kSums * 8));
+    HIPCHK(h, h->i_sums.reserve(kSums * 8));
+    h->s_stride = xyz_stride;
+    h->s_nstride = nrm_stride;
+    return REG_OK;
+}
+
+}  // extern "C"
+
+// =================================================================================================
+// iteration driver (host)
+// =================================================================================================
+
+static reg_status check_ready(reg_handle* h, bool need_prepared) {
+    if (!h) return REG_BAD_ARGUMENT;
+    if (!h->stream) return REG_DEVICE_ERROR;
+    if (h->m == 0) {
+        h->err = "no reference set (reg_set_target)";
+        return REG_NOT_CONFIGURED;
+    }
+    if (h->n == 0) {
+        h->err = "no reading set (reg_set_source)";
+        return REG_NOT_CONFIGURED;
+    }
+    if (need_prepared && !h->prepared) {
+        h->err = "reg_prepare has not been called for this reading";
+        return REG_NOT_CONFIGURED;
+    }
+    return REG_OK;
+}
+
+// R2
+static reg_status prepare_rowmajor(reg_handle* h, const float* T_init_row) {
+    reg_status s = check_ready(h, false);
+    if (s != REG_OK) return s;
+    if (!m4_is_finite(T_init_row)) {
+        h->err = "initial transformation contains non-finite values";
+        return REG_BAD_TRANSFORM;
+    }
+    HIPCHK(h, hipSetDevice(h->prm.device));
+    std::memcpy(h->T_init, T_init_row, 64);
+    const int64_t n = h->n;
+    if (h->prm.cost == REG_COST_P2PL) {
+        s = device_centroid(h, h->s_raw.as<float>(), h->s_stride, n, h->s_misc, h->c_read);
+        if (s != REG_OK) return s;
+        float A[16], B[16], tmp[16];
+        m4_identity(A);
+        m4_identity(B);
+        for (int k = 0; k < 3; ++k) {
+            A[4 * k + 3] = -h->c_ref[k];   // T_refIn_refMean^-1
+            B[4 * k + 3] = h->c_read[k];   // T_readIn_readMean
+        }
+        m4_mul(A, T_init_row, tmp);
+        m4_mul(tmp, B, h->T0);
+        k_prepare_source<<<grid_for(n), 256, 0, h->stream>>>(
+            h->s_raw.as<float>(), h->s_stride, h->has_snrm ? h->s_nrm_raw.as<float>() : nullptr, h->s_nstride, n,
+            h->c_read[0], h->c_read[1], h->c_read[2], make_xf(h->T0), 1, h->s_xyz.as<float4>(),
+            h->has_snrm ? h->s_nrm.as<float4>() : nullptr);
+    } else {
+        m4_identity(h->T0);
+        k_prepare_source<<<grid_for(n), 256, 0, h->stream>>>(h->s_raw.as<float>(), h->s_stride, nullptr, 3, n, 0.f, 0.f,
+                                                             0.f, make_xf(h->T0), 0, h->s_xyz.as<float4>(), nullptr);
+        k_pack_cov<<<grid_for(n), 256, 0, h->stream>>>(h->s_cov_raw.as<float>(), n, h->s_cov.as<float4>());
+    }
+    HIPCHK(h, hipGetLastError());
+    h->prepared = true;
+    h->have_match = false;
+    return REG_OK;
+}
+
+// R3+R4 (+ level-0 histogram when the trimmed filter is active)
+static reg_status enqueue_match(reg_handle* h, const float* T_row) {
+    const bool trim = h->prm.cost == REG_COST_P2PL && h->prm.use_trimmed;
+    if (trim) HIPCHK(h, hipMemsetAsync(h->i_hist.p, 0, 3 * 2048 * 4, h->stream));
+    k_match<<<h->n_blocks, 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->n, make_xf(T_row), h->grid, h->i_pos.as<int>(),
+                                                h->i_d2.as<float>(), trim ? h->i_hist.as<uint32_t>() : nullptr);
+    h->have_match = true;
+    return REG_OK;
+}
+
+// exact k-th smallest finite d2 (3 radix passes), result in SelectState::limit on the device
+static reg_status enqueue_select(reg_handle* h) {
+    uint32_t* hist = h->i_hist.as<uint32_t>();
+    SelectState* st = h->i_state.as<SelectState>();
+    HIPCHK(h, hipMemsetAsync(st, 0, sizeof(SelectState), h->stream));
+    const float ratio = h->prm.trim_ratio;
+    const int hb = std::min(h->n_blocks, 512);
+    k_select_pick<<<1, 256, 0, h->stream>>>(hist, 0, ratio, st);
+    k_select_hist<<<hb, 256, 0, h->stream>>>(h->i_d2.as<float>(), h->n, 1, st, hist + 2048);
+    k_select_pick<<<1, 256, 0, h->stream>>>(hist + 2048, 1, ratio, st);
+    k_select_hist<<<hb, 256, 0, h->stream>>>(h->i_d2.as<float>(), h->n, 2, st, hist + 4096);
+    k_select_pick<<<1, 256, 0, h->stream>>>(hist + 4096, 2, ratio, st);
+    return REG_OK;
+}
+
+static reg_status enqueue_linearize(reg_handle* h, const float* T_row, bool want_w) {
+    float* w = want_w ? h->i_w.as<float>() : nullptr;
+    if (h->prm.cost == REG_COST_P2PL) {
+        FilterCfg f;
+        f.use_trim = h->prm.use_trimmed;
+        f.use_normal = h->prm.use_surface_normal;
+        f.use_maxdist = h->prm.use_max_dist_filter;
+        f.cos_max_angle = std::cos(h->prm.max_normal_angle);  // cosf in T=float (OutlierFiltersImpl.cpp:229)
+        volatile float md = h->prm.outlier_max_dist;
+        f.outlier_max_d2 = md * md;
+        k_linearize_p2pl<<<h->n_blocks, 256, 0, h->stream>>>(
+            h->s_xyz.as<float4>(), h->has_snrm ? h->s_nrm.as<float4>() : nullptr, h->n, make_xf(T_row),
+            h->i_pos.as<int>(), h->i_d2.as<float>(), h->t_pts.as<float4>(), h->t_nrm.as<float4>(), f,
+            h->i_state.as<SelectState>(), w, h->i_partials.as<double>());
+    } else {
+        k_linearize_gicp<<<h->n_blocks, 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->s_cov.as<float4>(), h->n,
+                                                             make_xf(T_row), h->i_pos.as<int>(), h->i_d2.as<float>(),
+                                                             h->t_pts.as<float4>(), h->t_cov.as<float4>(), w,
+                                                             h->i_partials.as<double>());
+    }
+    k_final_reduce<<<1, 256, 0, h->stream>>>(h->i_partials.as<double>(), h->n_blocks, h->i_sums.as<double>());
+    return REG_OK;
+}
+
+// one full pass R3-R7 at T (row-major), sums -> h->h_sums (synchronises)
+static reg_status iterate_once(reg_handle* h, const float* T_row, bool want_w) {
+    reg_status s = enqueue_match(h, T_row);
+    if (s != REG_OK) return s;
+    if (h->prm.cost == REG_COST_P2PL && h->prm.use_trimmed) {
+        s = enqueue_select(h);
+        if (s != REG_OK) return s;
+    }
+    s = enqueue_linearize(h, T_row, want_w);
+    if (s != REG_OK) return s;
+    HIPCHK(h, hipMemcpyAsync(h->h_sums, h->i_sums.p, kSums * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    return REG_OK;
+}
+
+static void sums_to_system(const double* sums, bool p2pl, float* H, float* b) {
+    int k = 0;
+    for (int a = 0; a < 6; ++a)
+        for (int c = a; c < 6; ++c) {
+            const float v = (float)sums[k++];
+            H[6 * a + c] = v;
+            H[6 * c + a] = v;
+        }
+    for (int a = 0; a < 6; ++a) b[a] = p2pl ? -(float)sums[21 + a] : (float)sums[21 + a];
+}
+
+static void fill_result(reg_handle* h, const double* sums, reg_result* res) {
+    res->n_inliers = (int64_t)llround(sums[28]);
+    res->n_matched = (int64_t)llround(sums[29]);
+    res->error = sums[27];
+    res->fitness = h->n > 0 ? sums[28] / (double)h->n : 0.0;
+    res->inlier_rmse = sums[28] > 0 ? std::sqrt(sums[30] / sums[28]) : 0.0;
+    sums_to_system(sums, h->prm.cost == REG_COST_P2PL, res->H_last, res->b_last);
+    res->target_build_ms = h->target_build_ms;
+}
+
+extern "C" {
+
+reg_status reg_prepare(reg_handle* h, const float T_init[16]) {
+    if (!h || !T_init) return REG_BAD_ARGUMENT;
+    float Tr[16];
+    col_to_row(T_init, Tr);
+    return prepare_rowmajor(h, Tr);
+}
+
+reg_status reg_linearize(reg_handle* h, const float T_iter[16], float H[36], float b[6], double* err,
+                         int64_t* n_inliers) {
+    reg_status s = check_ready(h, true);
+    if (s != REG_OK) return s;
+    if (!T_iter) return REG_BAD_ARGUMENT;
+    float Tr[16];
+    col_to_row(T_iter, Tr);
+    if (!m4_is_finite(Tr)) return REG_BAD_TRANSFORM;
+    HIPCHK(h, hipSetDevice(h->prm.device));
+    s = iterate_once(h, Tr, true);
+    if (s != REG_OK) return s;
+    if (H && b) sums_to_system(h->h_sums, h->prm.cost == REG_COST_P2PL, H, b);
+    if (err) *err = h->h_sums[27];
+    if (n_inliers) *n_inliers = (int64_t)llround(h->h_sums[28]);
+    if (h->h_sums[28] == 0.0) {
+        h->err = "ErrorMinimizer: no point to minimize";
+        return REG_NO_CORRESPONDENCES;
+    }
+    return REG_OK;
+}
+
+reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], reg_result* res) {
+    if (!h || !T_init || !T_out) return REG_BAD_ARGUMENT;
+    reg_result local;
+    if (!res) res = &local;
+    std::memset(res, 0, sizeof(*res));
+    std::memcpy(T_out, T_init, 64);
+    float Ti[16];
+    col_to_row(T_init, Ti);
+    reg_status s = prepare_rowmajor(h, Ti);
+    if (s != REG_OK) return s;
+    const bool p2pl = h->prm.cost == REG_COST_P2PL;
+    const int fixed = h->prm.fixed_iters;
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    float T_iter[16];
+    double Td[16];
+    if (p2pl) {
+        m4_identity(T_iter);
+    } else {
+        std::memcpy(T_iter, Ti, 64);
+        for (int i = 0; i < 16; ++i) Td[i] = Ti[i];
+    }
+    Checkers chk;
+    chk.max_iter = h->prm.max_iter;
+    chk.min_diff_rot = h->prm.min_diff_rot;
+    chk.min_diff_trans = h->prm.min_diff_trans;
+    chk.smooth_len = h->prm.smooth_len;
+    chk.init(T_iter);
+    bool iterate = true;
+    int count = 0;
+    while (iterate) {
+        s = iterate_once(h, T_iter, false);
+        if (s != REG_OK) return s;
+        const double* sums = h->h_sums;
+        if (sums[28] == 0.0) {
+            h->err = sums[29] == 0.0 ? "No matches available for computing distance quantiles"
+                                     : "ErrorMinimizer: no point to minimize";
+            res->iterations = count;
+            fill_result(h, sums, res);
+            return REG_NO_CORRESPONDENCES;
+        }
+        float H[36], b[6];
+        sums_to_system(sums, p2pl, H, b);
+        if (p2pl) {
+            float x[6], dT[16];
+            res->rank_last = solve6_p2pl(H, b, x);
+            x_to_T(x, dT);
+            m4_mul(dT, T_iter, T_iter);  // T_iter = real * T_iter (ICP.cpp:1213-1215)
+            ++count;
+            if (fixed > 0)
+                iterate = count < fixed;
+            else
+                iterate = chk.check(T_iter);
+        } else {
+            double Hd[36], g[6], dl[6], E[16], Tn[16];
+            int k = 0;
+            for (int a = 0; a < 6; ++a)
+                for (int c = a; c < 6; ++c) {
+                    Hd[6 * a + c] = Hd[6 * c + a] = sums[k++];
+                }
+            for (int a = 0; a < 6; ++a) g[a] = -sums[21 + a];
+            res->rank_last = solve_sym6(Hd, g, dl, 1e-12);
+            se3_exp(dl, E);
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j) {
+                    double t = 0;
+                    for (int kk = 0; kk < 4; ++kk) t += Td[4 * i + kk] * E[4 * kk + j];
+                    Tn[4 * i + j] = t;
+                }
+            std::memcpy(Td, Tn, sizeof(Td));
+            for (int i = 0; i < 16; ++i) T_iter[i] = (float)Td[i];
+            ++count;
+            if (fixed > 0) {
+                iterate = count < fixed;
+            } else {
+                const double dr = std::sqrt(dl[0] * dl[0] + dl[1] * dl[1] + dl[2] * dl[2]);
+                const double dt = std::sqrt(dl[3] * dl[3] + dl[4] * dl[4] + dl[5] * dl[5]);
+                if (dr < h->prm.gicp_rot_eps && dt < h->prm.gicp_trans_eps) {
+                    chk.converged = true;
+                    iterate = false;
+                } else if (count >= h->prm.max_iter) {
+                    chk.max_iter_reached = true;
+                    iterate = false;
+                }
+            }
+        }
+    }
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipEventSynchronize(h->ev1));
+    (void)hipEventElapsedTime(&res->loop_ms, h->ev0, h->ev1);
+    res->iterations = count;
+    res->converged = chk.converged ? 1 : 0;
+    res->max_iter_reached = chk.max_iter_reached ? 1 : 0;
+    fill_result(h, h->h_sums, res);
+    float Tout_row[16];
+    if (p2pl) {
+        // R10: T = T_refIn_refMean * T_iter * T_refMean_readMean * T_readIn_readMean^-1 (ICP.cpp:1345)
+        float A[16], B[16], t1[16], t2[16];
+        m4_identity(A);
+        m4_identity(B);
+        for (int k = 0; k < 3; ++k) {
+            A[4 * k + 3] = h->c_ref[k];
+            B[4 * k + 3] = -h->c_read[k];
+        }
+        m4_mul(A, T_iter, t1);
+        m4_mul(t1, h->T0, t2);
+        m4_mul(t2, B, Tout_row);
+    } else {
+        std::memcpy(Tout_row, T_iter, 64);
+    }
+    row_to_col(Tout_row, T_out);
+    return REG_OK;
+}
+
+reg_status reg_compute(reg_handle* h, const float* xyz, int64_t xyz_stride, const float* nrm, int64_t nrm_stride,
+                       const float* cov, int64_t n, int on_device, const float T_init[16], float T_out[16],
+                       reg_result* res) {
+    reg_status s = reg_set_source(h, xyz, xyz_stride, nrm, nrm_stride, cov, n, on_device);
+    if (s != REG_OK) return s;
+    return reg_register(h, T_init, T_out, res);
+}
+
+reg_status reg_get_correspondences(reg_handle* h, int32_t* ids, float* d2, float* w) {
+    reg_status s = check_ready(h, true);
+    if (s != REG_OK) return s;
+    if (!h->have_match) {
+        h->err = "no iteration has run yet";
+        return REG_NOT_CONFIGURED;
+    }
+    HIPCHK(h, hipSetDevice(h->prm.device));
+    const int64_t n = h->n;
+    if (ids) {
+        HIPCHK(h, h->i_ids.reserve((size_t)n * 4));
+        k_ids_from_pos<<<grid_for(n), 256, 0, h->stream>>>(h->i_pos.as<int>(), h->t_pts.as<float4>(), n,
+                                                           h->i_ids.as<int32_t>());
+        HIPCHK(h, hipMemcpyAsync(ids, h->i_ids.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    }
+    if (d2) HIPCHK(h, hipMemcpyAsync(d2, h->i_d2.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    if (w) HIPCHK(h, hipMemcpyAsync(w, h->i_w.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return REG_OK;
+}
+
+// ---- distributed halves -------------------------------------------------------------------------
+
+reg_status reg_match_local(reg_handle* h, const float T_iter[16]) {
+    reg_status s = check_ready(h, true);
+    if (s != REG_OK) return s;
+    float Tr[16];
+    col_to_row(T_iter, Tr);
+    HIPCHK(h, hipSetDevice(h->prm.device));
+    s = enqueue_match(h, Tr);
+    if (s != REG_OK) return s;
+    HIPCHK(h, hipMemsetAsync(h->i_state.p, 0, sizeof(SelectState), h->stream));
+    return REG_OK;
+}
+
+reg_status reg_trim_histogram(reg_handle* h, int level, uint32_t prefix, uint32_t hist[2048]) {
+    reg_status s = check_ready(h, true);
+    if (s != REG_OK) return s;
+    if (level < 0 || level > 2 || !hist || !h->have_match) return REG_BAD_ARGUMENT;
+    HIPCHK(h, hipSetDevice(h->prm.device));
+    uint32_t* d_hist = h->i_hist.as<uint32_t>() + 2048 * level;
+    if (level > 0) {
+        SelectState st;
+        std::memset(&st, 0, sizeof(st));
+        st.prefix = prefix;
+        HIPCHK(h, hipMemcpyAsync(h->i_state.p, &st, sizeof(st), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemsetAsync(d_hist, 0, 2048 * 4, h->stream));
+        k_select_hist<<<std::min(h->n_blocks, 512), 256, 0, h->stream>>>(h->i_d2.as<float>(), h->n, level,
+                                                                         h->i_state.as<SelectState>(), d_hist);
+    }
+    HIPCHK(h, hipMemcpyAsync(hist, d_hist, 2048 * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return REG_OK;
+}
+
+reg_status reg_reduce_local(reg_handle* h, const float T_iter[16], float trim_limit, double sums[32]) {
+    reg_status s = check_ready(h, true);
+    if (s != REG_OK) return s;
+    if (!h->have_match || !sums || !T_iter) return REG_BAD_ARGUMENT;
+    float Tr[16];
+    col_to_row(T_iter, Tr);
+    HIPCHK(h, hipSetDevice(h->prm.device));
+    SelectState st;
+    std::memset(&st, 0, sizeof(st));
+    st.limit = trim_limit;
+    st.done = 1;
+    HIPCHK(h, hipMemcpyAsync(h->i_state.p, &st, sizeof(st), hipMemcpyHostToDevice, h->stream));
+    s = enqueue_linearize(h, Tr, true);
+    if (s != REG_OK) return s;
+    HIPCHK(h, hipMemcpyAsync(h->h_sums, h->i_sums.p, kSums * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    std::memcpy(sums, h->h_sums, kSums * 8);
+    return REG_OK;
+}
+
+// R8 (+ T_iter update) from globally summed sums; pure host code, identical on every rank.
+reg_status reg_solve_update(const reg_params* p, const double sums[32], const float T_iter[16], float T_next[16],
+                            int32_t* rank) {
+    if (!p || !sums || !T_iter || !T_next) return REG_BAD_ARGUMENT;
+    float Tr[16], H[36], b[6];
+    col_to_row(T_iter, Tr);
+    if (sums[28] == 0.0) return REG_NO_CORRESPONDENCES;
+    if (p->cost == REG_COST_P2PL) {
+        sums_to_system(sums, true, H, b);
+        float x[6], dT[16];
+        const int r = solve6_p2pl(H, b, x);
+        if (rank) *rank = r;
+        x_to_T(x, dT);
+        m4_mul(dT, Tr, Tr);
+    } else {
+        double Hd[36], g[6], dl[6], E[16], Tn[16];
+        int k = 0;
+        for (int a = 0; a < 6; ++a)
+            for (int c = a; c < 6; ++c) Hd[6 * a + c] = Hd[6 * c + a] = sums[k++];
+        for (int a = 0; a < 6; ++a) g[a] = -sums[21 + a];
+        const int r = solve_sym6(Hd, g, dl, 1e-12);
+        if (rank) *rank = r;
+        se3_exp(dl, E);
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) {
+                double t = 0;
+                for (int kk = 0; kk < 4; ++kk) t += (double)Tr[4 * i + kk] * E[4 * kk + j];
+                Tn[4 * i + j] = t;
+            }
+        for (int i = 0; i < 16; ++i) Tr[i] = (float)Tn[i];
+    }
+    row_to_col(Tr, T_next);
+    return REG_OK;
+}
+
+// ---- host-only exports ----------------------------------------------------------------------------
+
+int reg_host_solve6(const float A[36], const float b[6], float x[6]) { return solve6_p2pl(A, b, x); }
+
+void reg_host_x_to_T(const float x[6], float T[16]) {
+    float Tr[16];
+    x_to_T(x, Tr);
+    row_to_col(Tr, T);
+}
+
+void reg_host_centroid(const float* xyz, int64_t stride, int64_t n, float out[3]) {
+    long long s[3] = {0, 0, 0};
+    for (int64_t i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) s[k] += llrint((double)xyz[i * stride + k] * 65536.0);
+    for (int k = 0; k < 3; ++k) out[k] = n > 0 ? (float)((double)s[k] / (65536.0 * (double)n)) : 0.f;
+}
+
+}  // extern "C"

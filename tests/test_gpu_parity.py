@@ -1,0 +1,147 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle.  GPU box only.
+
+Tolerances (stated per SURVEY 8d / BASELINE.md):
+  * correspondence ids and squared distances: BIT-EXACT for the same transform;
+  * outlier weights: bit-exact (0/1);
+  * H, b (fp32): products fp32, sums fp64 on both sides -> rtol 1e-6 of the largest entry;
+  * final pose vs oracle: <= 1e-4 m and <= 1e-4 rad.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from open3d_slam_private_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _car():
+    ref = np.load(os.path.join(GOLD, "car_cloud400.npy"))
+    rd = np.load(os.path.join(GOLD, "car_cloud401.npy"))
+    return ref, rd
+
+
+def _oracle_iter0(tgt_xyz, tgt_nrm, src_xyz, src_nrm, T_init, max_dist, trim, angle):
+    """Replays R1-R7 of the oracle at T_iter = I and returns everything the HIP path exposes."""
+    c_ref = orc.centroid(tgt_xyz)
+    c_read = orc.centroid(src_xyz)
+    tgt_c = (tgt_xyz - c_ref).astype(np.float32)
+    return c_ref, c_read, tgt_c
+
+
+def _check_linearize(reg, tgt_xyz, tgt_nrm, src_xyz, src_nrm, max_dist, trim, angle, T_iter=None):
+    """Compare one linearisation at T_iter (centred frames) between HIP and oracle."""
+    T_iter = np.eye(4, dtype=np.float32) if T_iter is None else T_iter.astype(np.float32)
+    # oracle replay of R1/R2 (numeric contract: fl(x - c), T0 = inv(Tref) * T_init * Tread with T_init = I)
+    c_ref = orc.centroid(tgt_xyz)
+    c_read = orc.centroid(src_xyz)
+    tgt_c = tgt_xyz - c_ref
+    T0 = np.eye(4, dtype=np.float32)
+    # m4_mul(A, I) then (.)*B in fp32: translation = fl(-c_ref + c_read) per the row-by-column order
+    T0[:3, 3] = (np.float32(0) + (-c_ref)) if False else T0[:3, 3]
+    A = np.eye(4, dtype=np.float32); A[:3, 3] = -c_ref
+    B = np.eye(4, dtype=np.float32); B[:3, 3] = c_read
+    T0 = _m4(_m4(A, np.eye(4, dtype=np.float32)), B)
+    rd = _xf(T0, src_xyz - c_read)
+    rdn = _rot(T0, src_nrm) if src_nrm is not None else None
+    tree = orc.KdTree(tgt_c)
+    ids, d2 = tree.knn(rd, T_iter, max_dist=max_dist)
+    filt = orc.make_filters(trim_ratio=trim, max_normal_angle=angle)
+    w, limit = orc.weights(filt, rdn, tgt_nrm, T_iter, ids, d2)
+    A6, b6, err, kept = orc.p2pl_normal_eq(rd, tgt_c, tgt_nrm, T_iter, ids, d2, w)
+
+    H, b, gerr, gcnt = reg.linearize(T_iter)
+    gids, gd2, gw = reg.correspondences()
+    assert np.array_equal(gids, ids), f"{(gids != ids).sum()} correspondence ids differ"
+    assert np.array_equal(gd2.view(np.uint32), d2.view(np.uint32)), "squared distances not bit-exact"
+    assert np.array_equal(gw, w), f"{(gw != w).sum()} weights differ"
+    assert gcnt == kept
+    scale = np.abs(A6).max()
+    assert np.abs(H - A6).max() <= 1e-6 * scale, (np.abs(H - A6).max(), scale)
+    assert np.abs(b - b6).max() <= 1e-6 * max(np.abs(b6).max(), 1e-30) + 1e-7 * scale * 0
+    assert abs(gerr - err) <= 1e-9 * max(err, 1e-30)
+    return ids, d2, w
+
+
+def _m4(A, B):
+    C = np.zeros((4, 4), np.float32)
+    for i in range(4):
+        for j in range(4):
+            s = np.float32(A[i, 0] * B[0, j])
+            s = np.float32(s + np.float32(A[i, 1] * B[1, j]))
+            s = np.float32(s + np.float32(A[i, 2] * B[2, j]))
+            s = np.float32(s + np.float32(A[i, 3] * B[3, j]))
+            C[i, j] = s
+    return C
+
+
+def _xf(T, P):
+    T = T.astype(np.float32); P = P.astype(np.float32)
+    out = np.empty_like(P)
+    for i in range(3):
+        s = T[i, 0] * P[:, 0] + T[i, 1] * P[:, 1]
+        s = s + T[i, 2] * P[:, 2]
+        out[:, i] = s + T[i, 3]
+    return out
+
+
+def _rot(T, P):
+    T = T.astype(np.float32); P = P.astype(np.float32)
+    out = np.empty_like(P)
+    for i in range(3):
+        s = T[i, 0] * P[:, 0] + T[i, 1] * P[:, 1]
+        out[:, i] = s + T[i, 2] * P[:, 2]
+    return out
+
+
+def test_car_default_chain_matches_oracle_and_reference_known_answer():
+    ref, rd = _car()
+    p = capi.default_params()          # Trimmed 0.85, maxDist inf, Counter 40, Differential 1e-3/1e-3/3
+    reg = capi.Registration(p)
+    reg.set_target(ref[:, :3], ref[:, 3:6])
+    reg.set_source(rd)
+    T, res = reg.register(np.eye(4))
+    To, ores = orc.icp_p2pl(ref[:, :3], ref[:, 3:6], rd, trim_ratio=0.85, max_iter=40)
+    dt, dr = synth.pose_error(T, To)
+    assert res.iterations == ores.iterations
+    assert dt <= 1e-4 and dr <= 1e-4, (dt, dr)
+    # the reference's own acceptance test (utest.cpp:356-360, utest.h:65-86)
+    validT = np.load(os.path.join(GOLD, "validT3d.npy"))
+    assert abs(np.linalg.norm(T[:3, 3]) - np.linalg.norm(validT[:3, 3])) < 0.1
+    assert synth.pose_error(T, validT)[1] < 0.1
+
+
+def test_car_linearize_bit_exact_ids():
+    ref, rd = _car()
+    p = capi.default_params()
+    p.max_dist = 1.0
+    reg = capi.Registration(p)
+    reg.set_target(ref[:, :3], ref[:, 3:6])
+    reg.set_source(rd)
+    reg.prepare(np.eye(4))
+    _check_linearize(reg, ref[:, :3], ref[:, 3:6], rd, None, 1.0, 0.85, None)
+
+
+@pytest.mark.parametrize("n_src,n_tgt", [(5000, 50000), (20000, 200000)])
+def test_synth_shipped_chain(n_src, n_tgt):
+    sc = synth.make_scene(n_src, n_tgt, seed=1234)
+    p = capi.shipped_params()
+    reg = capi.Registration(p)
+    reg.set_target(sc.tgt_xyz, sc.tgt_nrm)
+    reg.set_source(sc.src_xyz, sc.src_nrm)
+    reg.prepare(np.eye(4))
+    _check_linearize(reg, sc.tgt_xyz, sc.tgt_nrm, sc.src_xyz, sc.src_nrm, 0.5, 0.9, 1.57)
+    T, res = reg.register(np.eye(4))
+    To, ores = orc.icp_p2pl(sc.tgt_xyz, sc.tgt_nrm, sc.src_xyz, sc.src_nrm, max_dist=0.5, trim_ratio=0.9,
+                            max_normal_angle=1.57, max_iter=30, min_diff_rot=0.001, min_diff_trans=0.008,
+                            smooth_len=3, n_threads=8)
+    dt, dr = synth.pose_error(T, To)
+    assert dt <= 1e-4 and dr <= 1e-4, (dt, dr)
+    # and the registration actually recovers the synthetic motion
+    dt, dr = synth.pose_error(T, sc.T_true)
+    assert dt < 5e-3 and dr < 1e-3, (dt, dr)
