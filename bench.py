@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Headline benchmark: ICP iterations/sec of scan-to-map registration on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3]
+
+A "step" is ONE registration of the synthetic scan against the synthetic map with exactly
+ITERS (=20) Gauss-Newton iterations of the reference's shipped chain (param/icp.yaml: knn 1, maxDist 0.5,
+TrimmedDist 0.9, SurfaceNormal 1.57, point-to-plane): R2 reading prep + 20 x (R3 transform, R4 exact 1-NN,
+R5 trimmed quantile + normal filter, R7 normal equations, R8 6x6 solve, R9 pose update) + R10.
+Inputs are resident in HBM before the timed region; the target voxel-bin build (== kd-tree build of the
+reference) is excluded on both sides and reported as target_build_ms.
+
+N=1: workload C2 (100k -> 1M points, BASELINE.json configs[1]).
+N>1: WEAK scaling -- every rank holds its own 100k-point slice of an N*100k-point reading (point
+partitioned), the 1M-point map is replicated; per iteration the ranks all-reduce the trimmed-quantile
+histograms and the 32-double (H, b, e, counts) record over RCCL.  `value` counts 100k-point iteration
+units: N_gpus * ITERS * K / t.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ITERS = 20
+WORKLOADS = {"c2": (100_000, 1_000_000, 1234 + 2), "c3": (200_000, 5_000_000, 1234 + 3),
+             "tiny": (10_000, 100_000, 1234 + 1)}
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+MATCH_BYTES_PER_POINT = 32   # k_match: src xyz 12 + matched tgt xyz 12 + pos 4 + d2 4
+ITER_BYTES_PER_POINT = 64    # P2Pl 48 B + 16 B (id, d2 written and re-read) for the split-kernel variant
+
+
+def cpu_baseline(sc, n_src, threads):
+    """The oracle (faithful C restatement; the reference itself cannot be built here) timed on the host cores:
+    same clouds, same chain, kd-tree build excluded.  Bounded sample: the first `n_src` reading points."""
+    from oracle import oracle as orc
+    out = {}
+    for name, nt, iters in (("omp", threads, ITERS), ("1t", 1, 4)):
+        _, r = orc.icp_p2pl(sc.tgt_xyz, sc.tgt_nrm, sc.src_xyz[:n_src], sc.src_nrm[:n_src], max_dist=0.5,
+                            trim_ratio=0.9, max_normal_angle=1.57, fixed_iters=iters, n_threads=nt)
+        out[name] = iters / r.loop_seconds
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with WORLD_SIZE={args.gpus} (got {world})")
+
+    import torch  # plumbing only: device buffers, streams, torch.distributed
+    from open3d_slam_private_amd import capi, synth
+    from open3d_slam_private_amd.distributed import DistributedRegistration
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the registration path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    n_src, n_tgt, seed = WORKLOADS[args.workload]
+    sc = synth.make_scene(n_src * world, n_tgt, seed=seed)
+    lo, hi = rank * n_src, (rank + 1) * n_src
+
+    # inputs resident in HBM before anything is timed
+    d_tgt = torch.from_numpy(sc.tgt_xyz).to(dev)
+    d_tnrm = torch.from_numpy(sc.tgt_nrm).to(dev)
+    d_src = torch.from_numpy(sc.src_xyz[lo:hi]).to(dev)
+    d_snrm = torch.from_numpy(sc.src_nrm[lo:hi]).to(dev)
+    torch.cuda.synchronize()
+
+    p = capi.shipped_params()
+    p.fixed_iters = ITERS
+    p.device = local_rank
+    reg = capi.Registration(p)
+    reg.set_target_device(d_tgt.data_ptr(), 3, n_tgt, d_tnrm.data_ptr(), 3)
+    reg.set_source_device(d_src.data_ptr(), 3, n_src, d_snrm.data_ptr(), 3)
+    info = reg.target_info()
+    T_init = np.eye(4, dtype=np.float32)
+
+    if world == 1:
+        def step():
+            return reg.register(T_init)
+    else:
+        def solve(sums, T):
+            return capi.solve_update(p, sums, T)[0]
+        dreg = DistributedRegistration(reg, solve, True, p.trim_ratio, ITERS, dist=dist, device=dev)
+
+        def step():
+            s = torch.from_numpy(reg.source_centroid_sums()).to(dev)
+            dist.all_reduce(s)
+            c = (s.cpu().numpy().astype(np.float64) / (65536.0 * n_src * world)).astype(np.float32)
+            reg.prepare_centroid(T_init, c)
+            T_iter, sums = dreg.run()
+            return reg.compose(T_iter), sums
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    T_final = out[0]
+
+    # kernel-level numbers (outside the timed region): HIP events on the handle's own stream
+    reg.prepare(T_init) if world == 1 else None
+    prof = reg.profile_kernels(np.eye(4, dtype=np.float32), reps=20)
+    match_s = prof["match_ms"] * 1e-3
+    achieved = n_src * MATCH_BYTES_PER_POINT / match_s / 1e9
+    iter_s = (prof["match_ms"] + prof["select_ms"] + prof["linearize_ms"]) * 1e-3
+
+    if rank == 0:
+        value = world * ITERS * args.steps / elapsed
+        line = {
+            "metric": "ICP iterations/sec (scan-to-map, 100k-point reading units)",
+            "value": value, "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: scan-to-map point-to-plane ICP {n_src}x{world} -> {n_tgt} points, "
+                                   f"{ITERS} iterations/registration, shipped icp.yaml chain (exact 1-NN, maxDist 0.5, "
+                                   "Trimmed 0.9, SurfaceNormal 1.57)",
+                       "n_source_per_gpu": n_src, "n_target": n_tgt, "iterations_per_step": ITERS,
+                       "parallelism": f"point-partitioned x{world}" if world > 1 else "single GPU",
+                       "cell_size_m": info.cell_size, "n_bricks": info.n_bricks},
+            "roofline": {"bound": "hbm", "kernel": "k_match", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms": prof["match_ms"], "bytes_per_point": MATCH_BYTES_PER_POINT},
+            "roofline_iteration": {"bytes_per_point": ITER_BYTES_PER_POINT,
+                                   "achieved_GBs_kernels_only": n_src * ITER_BYTES_PER_POINT / iter_s / 1e9,
+                                   "achieved_GBs_end_to_end": n_src * ITER_BYTES_PER_POINT * ITERS * args.steps / elapsed / 1e9,
+                                   "match_ms": prof["match_ms"], "select_ms": prof["select_ms"],
+                                   "linearize_ms": prof["linearize_ms"]},
+            "target_build_ms": float(reg.last_result.target_build_ms) if world == 1 else None,
+        }
+        if not args.no_cpu_baseline:
+            cores = os.cpu_count() or 1
+            threads = min(cores, 64)
+            cb = cpu_baseline(sc, n_src, threads)
+            line["cpu_baseline"] = {"value": cb["omp"], "unit": "iter/s", "cores": threads, "kind": "port",
+                                    "sample": f"same {n_src}->{n_tgt} clouds and chain, {ITERS} iterations once, "
+                                              "OpenMP oracle (kd-tree build excluded)",
+                                    "value_1thread": cb["1t"]}
+            line["speedup_vs_cpu_omp"] = value / world / cb["omp"]
+            # final-pose parity against the oracle on the same inputs (whole reading)
+            from oracle import oracle as orc
+            To, _ = orc.icp_p2pl(sc.tgt_xyz, sc.tgt_nrm, sc.src_xyz, sc.src_nrm, max_dist=0.5, trim_ratio=0.9,
+                                 max_normal_angle=1.57, fixed_iters=ITERS, n_threads=threads)
+            dt, dr = synth.pose_error(T_final, To)
+            et, er = synth.pose_error(T_final, sc.T_true)
+            line["pose_vs_oracle"] = {"trans_m": dt, "rot_rad": dr}
+            line["pose_vs_truth"] = {"trans_m": et, "rot_rad": er}
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

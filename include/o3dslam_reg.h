@@ -87,7 +87,8 @@ typedef struct {
     float   cell_size;          /* voxel-bin edge in metres; 0 = choose from target density */
     int32_t device;             /* HIP device ordinal */
     int32_t sort_source;        /* 1: Morton-order the reading on upload (speed only; results in input order) */
-    int32_t reserved[7];
+    int32_t match_variant;      /* 0: 8 lanes per reading point + level hints (default); 1: one lane per point; 2: 8 lanes, no hints; 3: as 0 with the level-0 histogram fused into the match kernel */
+    int32_t reserved[6];
 } reg_params;
 
 typedef struct {
@@ -104,6 +105,7 @@ typedef struct {
     float   b_last[6];
     float   target_build_ms;    /* last reg_set_target: upload + voxel-bin build */
     float   loop_ms;            /* iteration loop of the last reg_register (device time, HIP events) */
+    float   T_iter_last[16];    /* final T_iter (column-major): P2PL in the centred frames, GICP == T_out */
 } reg_result;
 
 /* ICPChainBase::setDefault (ICP.cpp:100-113): knn 1, eps 0, maxDist inf, Trimmed 0.85,
@@ -160,6 +162,9 @@ REG_API reg_status reg_get_correspondences(reg_handle* h, int32_t* ids, float* d
                          of finite d2 (level 0..2; prefix = bits fixed by previous levels).
    reg_reduce_local    : R5-R7 given the global trim limit -> 32 doubles {21 upper-tri H, 6 b, err, n_in, n_matched, sum d2 inliers, pad}.
    reg_apply_update    : R8+R9 from the globally summed 32 doubles (identical on every rank). */
+REG_API reg_status reg_source_centroid_sums(reg_handle* h, int64_t sums[3]);   /* sum llrint(x*2^16): exact, order-free */
+REG_API reg_status reg_prepare_centroid(reg_handle* h, const float T_init[16], const float c_read[3]); /* R2 with the GLOBAL reading centroid */
+REG_API reg_status reg_compose(reg_handle* h, const float T_iter[16], float T_out[16]);              /* R10 */
 REG_API reg_status reg_match_local(reg_handle* h, const float T_iter[16]);
 REG_API reg_status reg_trim_histogram(reg_handle* h, int level, uint32_t prefix, uint32_t hist[2048]);
 REG_API reg_status reg_reduce_local(reg_handle* h, const float T_iter[16], float trim_limit, double sums[32]);
@@ -171,6 +176,10 @@ REG_API reg_status reg_solve_update(const reg_params* p, const double sums[32], 
 REG_API int  reg_host_solve6(const float A[36], const float b[6], float x[6]);
 REG_API void reg_host_x_to_T(const float x[6], float T[16]);
 REG_API void reg_host_centroid(const float* xyz, int64_t stride, int64_t n, float out[3]);
+
+/* Measurement hook (bench.py roofline object): average device time in ms, by HIP events on the handle's
+   stream, of [0] the match kernel, [1] the trimmed-quantile select passes, [2] linearize + final reduce. */
+REG_API reg_status reg_profile_kernels(reg_handle* h, const float T_iter[16], int reps, float ms[3]);
 
 /* Introspection of the search structure (tests, DESIGN.md numbers). */
 typedef struct {

@@ -32,14 +32,15 @@ class RegParams(C.Structure):
                 ("min_diff_rot", C.c_float), ("min_diff_trans", C.c_float), ("smooth_len", C.c_int32),
                 ("fixed_iters", C.c_int32), ("gicp_rot_eps", C.c_float), ("gicp_trans_eps", C.c_float),
                 ("cell_size", C.c_float), ("device", C.c_int32), ("sort_source", C.c_int32),
-                ("reserved", C.c_int32 * 7)]
+                ("match_variant", C.c_int32), ("reserved", C.c_int32 * 6)]
 
 
 class RegResult(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32), ("max_iter_reached", C.c_int32),
                 ("rank_last", C.c_int32), ("n_inliers", C.c_int64), ("n_matched", C.c_int64), ("error", C.c_double),
                 ("fitness", C.c_double), ("inlier_rmse", C.c_double), ("H_last", C.c_float * 36),
-                ("b_last", C.c_float * 6), ("target_build_ms", C.c_float), ("loop_ms", C.c_float)]
+                ("b_last", C.c_float * 6), ("target_build_ms", C.c_float), ("loop_ms", C.c_float),
+                ("T_iter_last", C.c_float * 16)]
 
 
 class TargetInfo(C.Structure):
@@ -51,7 +52,7 @@ class TargetInfo(C.Structure):
 EXPORTS = ["reg_default_params", "reg_shipped_params", "reg_create", "reg_destroy", "reg_last_error",
            "reg_set_stream", "reg_set_target", "reg_set_source", "reg_register", "reg_compute", "reg_prepare",
            "reg_linearize", "reg_get_correspondences", "reg_match_local", "reg_trim_histogram", "reg_reduce_local",
-           "reg_solve_update", "reg_host_solve6", "reg_host_x_to_T", "reg_host_centroid", "reg_get_target_info"]
+           "reg_solve_update", "reg_host_solve6", "reg_host_x_to_T", "reg_host_centroid", "reg_get_target_info", "reg_profile_kernels", "reg_source_centroid_sums", "reg_prepare_centroid", "reg_compose"]
 
 
 def lib_path() -> str:
@@ -102,6 +103,10 @@ def load_library():
     lib.reg_host_x_to_T.argtypes = [f32p, f32p]
     lib.reg_host_centroid.argtypes = [f32p, i64, i64, f32p]
     lib.reg_get_target_info.argtypes = [vp, C.POINTER(TargetInfo)]
+    lib.reg_profile_kernels.argtypes = [vp, f32p, C.c_int, f32p]
+    lib.reg_source_centroid_sums.argtypes = [vp, vp]
+    lib.reg_prepare_centroid.argtypes = [vp, f32p, f32p]
+    lib.reg_compose.argtypes = [vp, f32p, f32p]
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError if the library does not export what the header declares
     _lib = lib
@@ -245,7 +250,27 @@ class Registration:
         self._check(self._lib.reg_get_target_info(self._h, C.byref(info)))
         return info
 
+    def profile_kernels(self, T_iter=None, reps=20):
+        ms = np.zeros(3, np.float32)
+        Ti = _T_in(np.eye(4) if T_iter is None else T_iter)
+        self._check(self._lib.reg_profile_kernels(self._h, _ptr(Ti), reps, _ptr(ms)))
+        return {"match_ms": float(ms[0]), "select_ms": float(ms[1]), "linearize_ms": float(ms[2])}
+
     # ---- distributed halves ---------------------------------------------------------------------
+    def source_centroid_sums(self):
+        s = np.zeros(3, np.int64)
+        self._check(self._lib.reg_source_centroid_sums(self._h, _ptr(s)))
+        return s
+
+    def prepare_centroid(self, T_init, c_read):
+        c = np.ascontiguousarray(c_read, np.float32)
+        self._check(self._lib.reg_prepare_centroid(self._h, _ptr(_T_in(T_init)), _ptr(c)))
+
+    def compose(self, T_iter):
+        To = np.zeros(16, np.float32)
+        self._check(self._lib.reg_compose(self._h, _ptr(_T_in(T_iter)), _ptr(To)))
+        return _T_out(To)
+
     def match_local(self, T_iter):
         self._check(self._lib.reg_match_local(self._h, _ptr(_T_in(T_iter))))
 

@@ -162,13 +162,45 @@ __global__ void k_fill_tables(const uint64_t* __restrict__ keys, const uint32_t*
 // kernels: reading preparation (R2)
 // =================================================================================================
 
-// reading' = T0 * (p - c_read), normals' = R0 * n  (ICP.cpp:966-984)
-__global__ void k_prepare_source(const float* __restrict__ xyz, int64_t stride, const float* __restrict__ nrm,
-                                 int64_t nrm_stride, int64_t n, float cx, float cy, float cz, Xf T0, int centre,
-                                 float4* __restrict__ out_xyz, float4* __restrict__ out_nrm) {
+// Morton key of the bin the (pre-transformed) reading point falls into: neighbouring lanes then search
+// neighbouring bins (speed only -- results are reported in the caller's order).
+__device__ __forceinline__ uint32_t spread10(uint32_t v) {
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+__global__ void k_source_keys(const float* __restrict__ xyz, int64_t stride, int64_t n, float cx, float cy, float cz,
+                              Xf T0, int centre, float ox, float oy, float oz, float inv_c, float dimx, float dimy,
+                              float dimz, int shift, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* p = xyz + i * stride;
+    float x = p[0], y = p[1], z = p[2];
+    if (centre) {
+        x = x - cx;
+        y = y - cy;
+        z = z - cz;
+    }
+    const float3 q = xf_point(T0, x, y, z);
+    const uint32_t bx = (uint32_t)fminf(fmaxf(bin_coord_f(q.x, ox, inv_c), 0.f), dimx - 1.f) >> shift;
+    const uint32_t by = (uint32_t)fminf(fmaxf(bin_coord_f(q.y, oy, inv_c), 0.f), dimy - 1.f) >> shift;
+    const uint32_t bz = (uint32_t)fminf(fmaxf(bin_coord_f(q.z, oz, inv_c), 0.f), dimz - 1.f) >> shift;
+    keys[i] = spread10(bx) | (spread10(by) << 1) | (spread10(bz) << 2);
+    vals[i] = (uint32_t)i;
+}
+
+// reading' = T0 * (p - c_read), normals' = R0 * n  (ICP.cpp:966-984); slot i holds input point perm[i]
+__global__ void k_prepare_source(const float* __restrict__ xyz, int64_t stride, const float* __restrict__ nrm,
+                                 int64_t nrm_stride, int64_t n, float cx, float cy, float cz, Xf T0, int centre,
+                                 const uint32_t* __restrict__ perm, float4* __restrict__ out_xyz,
+                                 float4* __restrict__ out_nrm) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t src = perm ? (int64_t)perm[i] : i;
+    const float* p = xyz + src * stride;
     float x = p[0], y = p[1], z = p[2];
     if (centre) {
         x = x - cx;
@@ -179,17 +211,18 @@ __global__ void k_prepare_source(const float* __restrict__ xyz, int64_t stride, 
     }
     out_xyz[i] = make_float4(x, y, z, 1.f);
     if (out_nrm) {
-        const float* q = nrm + i * nrm_stride;
+        const float* q = nrm + src * nrm_stride;
         float3 r = make_float3(q[0], q[1], q[2]);
         if (centre) r = xf_rot(T0, r.x, r.y, r.z);
         out_nrm[i] = make_float4(r.x, r.y, r.z, 0.f);
     }
 }
 
-__global__ void k_pack_cov(const float* __restrict__ cov, int64_t n, float4* __restrict__ out) {
+__global__ void k_pack_cov(const float* __restrict__ cov, int64_t n, const uint32_t* __restrict__ perm,
+                           float4* __restrict__ out) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float* q = cov + i * 6;
+    const float* q = cov + (perm ? (int64_t)perm[i] : i) * 6;
     out[2 * i] = make_float4(q[0], q[1], q[2], q[3]);
     out[2 * i + 1] = make_float4(q[4], q[5], 0.f, 0.f);
 }
@@ -203,8 +236,10 @@ __global__ void k_pack_cov(const float* __restrict__ cov, int64_t n, float4* __r
 // level-0 radix histogram (top 11 bits) of the finite distances for the trimmed-quantile select.
 __global__ void __launch_bounds__(256)
 k_match(const float4* __restrict__ src, int64_t n, Xf T, Grid g, int* __restrict__ pos, float* __restrict__ d2,
-        uint32_t* __restrict__ hist0 /* 2048 or null */) {
+        uint32_t* __restrict__ hist0 /* 2048 or null */, uint32_t* __restrict__ hist2_to_zero, int shift0) {
     __shared__ uint32_t sh[2048];
+    if (hist2_to_zero && blockIdx.x == 0)
+        for (int k = threadIdx.x; k < 2048; k += blockDim.x) hist2_to_zero[k] = 0;
     if (hist0) {
         for (int k = threadIdx.x; k < 2048; k += blockDim.x) sh[k] = 0;
         __syncthreads();
@@ -216,7 +251,43 @@ k_match(const float4* __restrict__ src, int64_t n, Xf T, Grid g, int* __restrict
         const Best b = nearest(g, p);
         pos[i] = b.pos;
         d2[i] = b.pos >= 0 ? b.d2 : INFINITY;
-        if (hist0 && b.pos >= 0) atomicAdd(&sh[__float_as_uint(b.d2) >> 21], 1u);
+        if (hist0 && b.pos >= 0) atomicAdd(&sh[__float_as_uint(b.d2) >> shift0], 1u);
+    }
+    if (hist0) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < 2048; k += blockDim.x)
+            if (sh[k]) atomicAdd(&hist0[k], sh[k]);
+    }
+}
+
+// Cooperative variant: 8 lanes per reading point (32 points per 256-thread workgroup).
+// `hint` (one byte per point, may be null) carries the terminating level of the previous iteration.
+__global__ void __launch_bounds__(256)
+k_match_g8(const float4* __restrict__ src, int64_t n, Xf T, Grid g, int* __restrict__ pos, float* __restrict__ d2,
+           uint32_t* __restrict__ hist0 /* 2048 or null */, uint32_t* __restrict__ hist2_to_zero,
+           uint8_t* __restrict__ hint, int shift0) {
+    __shared__ uint32_t sh[2048];
+    if (hist2_to_zero && blockIdx.x == 0)
+        for (int k = threadIdx.x; k < 2048; k += blockDim.x) hist2_to_zero[k] = 0;
+    if (hist0) {
+        for (int k = threadIdx.x; k < 2048; k += blockDim.x) sh[k] = 0;
+        __syncthreads();
+    }
+    const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t q = tid >> 3;
+    const int sub = (int)(tid & (kGroup - 1));
+    if (q < n) {
+        const float4 s = src[q];
+        const float3 p = xf_point(T, s.x, s.y, s.z);
+        const int first = hint ? max((int)hint[q] - 1, 0) : 0;
+        int lvl;
+        const Best b = nearest_group(g, p, sub, first, &lvl);
+        if (sub == 0) {
+            pos[q] = b.pos;
+            d2[q] = b.pos >= 0 ? b.d2 : INFINITY;
+            if (hint) hint[q] = (uint8_t)lvl;
+            if (hist0 && b.pos >= 0) atomicAdd(&sh[__float_as_uint(b.d2) >> shift0], 1u);
+        }
     }
     if (hist0) {
         __syncthreads();
@@ -235,91 +306,148 @@ struct SelectState {
     uint32_t pad[3];
 };
 
-// level 0: bits [31:21], level 1: [20:10], level 2: [9:0]
-__global__ void k_select_pick(const uint32_t* __restrict__ hist, int level, float ratio, SelectState* st) {
-    __shared__ uint32_t sh[2048];
-    __shared__ uint32_t wave_tot[4];
-    const int nb = level == 2 ? 1024 : 2048;
-    // 256 threads, 8 bins each
+// Exact trimmed-quantile select (Matches.cpp:60-87) as a 3-level radix select on the fp32 bit pattern
+// (d2 >= 0, so the pattern is monotone): level 0 = bits [31:21] (histogram built by the match kernel),
+// level 1 = bits [20:10], level 2 = bits [9:0].  No single-workgroup pass: every workgroup of the
+// NEXT kernel re-derives the bin picked at the previous level from the (tiny) global histogram.
+
+// Block-wide (256 threads): bin b with cum[b] <= rank < cum[b+1] over hist[0..nb), nb <= 2048.
+// Returns through LDS: out[0] = bin, out[1] = rank inside the bin, out[2] = total count.
+__device__ __forceinline__ void block_pick256(const uint32_t* __restrict__ hist, int nb, uint32_t rank,
+                                              uint32_t* wave_tot /*[4]*/, uint32_t* out /*[3]*/) {
+    const int t = threadIdx.x;
     uint32_t loc[8];
     uint32_t sum = 0;
+#pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const int b = threadIdx.x * 8 + k;
-        loc[k] = b < nb ? hist[b] : 0u;
+        const int bin = t * 8 + k;
+        loc[k] = bin < nb ? hist[bin] : 0u;
         sum += loc[k];
     }
-    // block exclusive scan of per-thread sums
     uint32_t incl = sum;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = t & 63, wave = t >> 6;
     for (int o = 1; o < 64; o <<= 1) {
         const uint32_t v = __shfl_up(incl, o);
         if (lane >= o) incl += v;
     }
     if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
-    uint32_t base = 0;
-    for (int w = 0; w < wave; ++w) base += wave_tot[w];
-    uint32_t excl = base + incl - sum;
-    __shared__ uint32_t s_rank, s_total;
-    if (threadIdx.x == 0) {
-        const uint32_t total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
-        s_total = total;
-        if (level == 0) {
-            st->n_finite = total;
-            uint32_t r;
-            if (ratio == 1.0f) {
-                r = total ? total - 1 : 0;
-            } else {
-                // `values.size() * quantile` evaluated in float, truncated (Matches.cpp:85-86)
-                const float posf = (float)total * ratio;
-                r = (uint32_t)posf;
-                if (total && r >= total) r = total - 1;
-            }
-            s_rank = r;
-        } else {
-            s_rank = st->rank;
-        }
+    if (t == 0) {
+        out[0] = 0;
+        out[1] = 0;
     }
-    (void)sh;
     __syncthreads();
-    const uint32_t rank = s_rank;
-    if (s_total == 0) {
-        if (threadIdx.x == 0) {
-            st->limit = INFINITY;
-            st->done = 1;
-        }
-        return;
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const uint32_t v = wave_tot[w];
+        if (w < wave) base += v;
+        total += v;
     }
-    // the bin whose [excl, excl+count) range contains `rank`
-    uint32_t run = excl;
+    if (t == 0) out[2] = total;
+    uint32_t run = base + incl - sum;
+#pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const int b = threadIdx.x * 8 + k;
-        if (b < nb && loc[k] && rank >= run && rank < run + loc[k]) {
-            const uint32_t shift = level == 0 ? 21 : (level == 1 ? 10 : 0);
-            const uint32_t prefix = (level == 0 ? 0u : st->prefix) | ((uint32_t)b << shift);
-            st->prefix = prefix;
-            st->rank = rank - run;
-            if (level == 2) {
-                st->limit = __uint_as_float(prefix);
-                st->done = 1;
-            }
+        if (loc[k] && rank >= run && rank < run + loc[k]) {
+            out[0] = (uint32_t)(t * 8 + k);
+            out[1] = rank - run;
         }
         run += loc[k];
     }
+    __syncthreads();
 }
 
+// Matches.cpp:82-86: index = size()*quantile evaluated in float, truncated; quantile == 1 -> maximum.
+__device__ __forceinline__ uint32_t trim_rank(uint32_t total, float ratio) {
+    if (total == 0) return 0;
+    if (ratio == 1.0f) return total - 1;
+    const float posf = (float)total * ratio;
+    uint32_t r = (uint32_t)posf;
+    return r >= total ? total - 1 : r;
+}
+
+// level = 1: pick level 0 from hist_prev (= hist0), histogram bits [20:10] into hist_out, zero nothing.
+// level = 2: pick level 1 from hist_prev (= hist1) using the state, histogram bits [9:0]; zero `to_zero`.
 __global__ void __launch_bounds__(256)
-k_select_hist(const float* __restrict__ d2, int64_t n, int level, const SelectState* __restrict__ st,
-              uint32_t* __restrict__ hist) {
+k_select_level(const float* __restrict__ d2, int64_t n, int level, int shift0, float ratio, const uint32_t* __restrict__ hist_prev,
+               uint32_t* __restrict__ hist_out, uint32_t* __restrict__ to_zero, SelectState* st) {
     __shared__ uint32_t sh[2048];
+    __shared__ uint32_t wave_tot[4];
+    __shared__ uint32_t pick[3];
     for (int k = threadIdx.x; k < 2048; k += blockDim.x) sh[k] = 0;
+    uint32_t prefix, rank_in;
+    if (level == 1) {
+        // total count of finite distances = sum of hist0
+        block_pick256(hist_prev, 2048, 0xffffffffu, wave_tot, pick);
+        const uint32_t total = pick[2];
+        __syncthreads();
+        block_pick256(hist_prev, 2048, trim_rank(total, ratio), wave_tot, pick);
+        prefix = pick[0] << shift0;
+        rank_in = pick[1];
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            st->n_finite = total;
+            st->prefix = prefix;
+            st->rank = rank_in;
+            if (total == 0) st->limit = INFINITY;
+        }
+    } else {
+        block_pick256(hist_prev, 2048, st->rank, wave_tot, pick);
+        prefix = st->prefix | (pick[0] << (shift0 - 11));
+        rank_in = pick[1];
+    }
     __syncthreads();
-    const uint32_t prefix = st->prefix;
-    const uint32_t mask = level == 1 ? 0xffe00000u : 0xfffffc00u;
+    const int s1 = shift0 - 11;  // low bit of the level-1 digit; level 2 = the s1 lowest bits
+    const uint32_t mask = level == 1 ? ~((1u << shift0) - 1u) : ~((1u << s1) - 1u);
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const uint32_t u = __float_as_uint(d2[i]);
         if (u != 0x7f800000u && (u & mask) == prefix) {
-            const uint32_t b = level == 1 ? ((u >> 10) & 2047u) : (u & 1023u);
+            const uint32_t b = level == 1 ? ((u >> s1) & 2047u) : (u & ((1u << s1) - 1u));
+            atomicAdd(&sh[b], 1u);
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 2048; k += blockDim.x)
+        if (sh[k]) atomicAdd(&hist_out[k], sh[k]);
+    if (blockIdx.x == 0) {
+        if (to_zero)
+            for (int k = threadIdx.x; k < 2048; k += blockDim.x) to_zero[k] = 0;
+        if (level == 2 && threadIdx.x == 0) {
+            // the state is only read by later kernels
+        }
+    }
+    // publish the level-2 prefix/rank for the linearize kernel (kernel boundary orders it)
+    if (level == 2 && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        st->pad[0] = prefix;    // 22 fixed bits
+        st->pad[1] = rank_in;   // rank inside that bucket
+    }
+}
+
+// Level-0 histogram of the single-GPU pipeline (digit = bits [shift0+10 : shift0]).  A separate pass with
+// few workgroups: folding it into the match kernel costs ~10^5 global atomics (~25-40 us on MI355X).
+__global__ void __launch_bounds__(256)
+k_hist_level0(const float* __restrict__ d2, int64_t n, int shift0, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t sh[2048];
+    for (int k = threadIdx.x; k < 2048; k += blockDim.x) sh[k] = 0;
+    __syncthreads();
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t u = __float_as_uint(d2[i]);
+        if (u != 0x7f800000u) atomicAdd(&sh[u >> shift0], 1u);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 2048; k += blockDim.x)
+        if (sh[k]) atomicAdd(&hist[k], sh[k]);
+}
+
+// Histogram of one radix level for a caller-supplied prefix (distributed path: the ranks sum these).
+__global__ void __launch_bounds__(256)
+k_hist_prefix(const float* __restrict__ d2, int64_t n, int level, uint32_t prefix, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t sh[2048];
+    for (int k = threadIdx.x; k < 2048; k += blockDim.x) sh[k] = 0;
+    __syncthreads();
+    const uint32_t mask = level == 0 ? 0u : (level == 1 ? 0xffe00000u : 0xfffffc00u);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t u = __float_as_uint(d2[i]);
+        if (u != 0x7f800000u && (u & mask) == prefix) {
+            const uint32_t b = level == 0 ? (u >> 21) : (level == 1 ? ((u >> 10) & 2047u) : (u & 1023u));
             atomicAdd(&sh[b], 1u);
         }
     }
@@ -349,21 +477,30 @@ __device__ __forceinline__ float3 normalize3(float3 n) {
     return n;
 }
 
-// wave-level sum of a double over 64 lanes
-__device__ __forceinline__ double wave_sum(double v) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-    return v;
+// Reduce kSums (=32) doubles per lane over the 64 lanes of a wave with 32 shuffles instead of 192:
+// at every step a lane keeps one half of its values and hands the other half to its xor-partner.
+// On return lanes 2c and 2c+1 both hold the wave total of component c in v[0].
+__device__ __forceinline__ void wave_reduce32(double* v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int half = 16, bit = 32; half >= 1; half >>= 1, bit >>= 1) {
+        const bool up = (lane & bit) != 0;
+#pragma unroll
+        for (int k = 0; k < half; ++k) {
+            const double keep = up ? v[k + half] : v[k];
+            const double send = up ? v[k] : v[k + half];
+            v[k] = keep + __shfl_xor(send, bit);
+        }
+    }
+    v[0] = v[0] + __shfl_xor(v[0], 1);
 }
 
-// block partial -> global: partials[blockIdx.x][kSums]
+// block partial -> global: partials[blockIdx.x][kSums]  (256 threads = 4 waves)
 __device__ __forceinline__ void block_reduce_store(double* vals /* kSums per thread */, double* __restrict__ partials) {
     __shared__ double sh[4][kSums];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < kSums; ++k) {
-        const double s = wave_sum(vals[k]);
-        if (lane == 0) sh[wave][k] = s;
-    }
+    wave_reduce32(vals);
+    if ((lane & 1) == 0) sh[wave][lane >> 1] = vals[0];
     __syncthreads();
     if (threadIdx.x < kSums) {
         double t = 0;
@@ -377,8 +514,26 @@ __device__ __forceinline__ void block_reduce_store(double* vals /* kSums per thr
 __global__ void __launch_bounds__(256)
 k_linearize_p2pl(const float4* __restrict__ src, const float4* __restrict__ src_nrm, int64_t n, Xf T,
                  const int* __restrict__ pos, const float* __restrict__ d2, const float4* __restrict__ tgt,
-                 const float4* __restrict__ tgt_nrm, FilterCfg f, const SelectState* __restrict__ st,
+                 const float4* __restrict__ tgt_nrm, FilterCfg f, SelectState* __restrict__ st,
+                 const uint32_t* __restrict__ hist2, uint32_t* __restrict__ hist1_to_zero, int shift0,
                  float* __restrict__ w_out, double* __restrict__ partials) {
+    // trimmed-quantile limit: last radix level, re-derived by every workgroup (f.use_trim == 2),
+    // or taken from the state as given by the caller (f.use_trim == 1: distributed path)
+    float limit = INFINITY;
+    if (f.use_trim == 2) {
+        __shared__ uint32_t wave_tot[4];
+        __shared__ uint32_t pick[3];
+        if (st->n_finite != 0) {
+            block_pick256(hist2, 1 << (shift0 - 11), st->pad[1], wave_tot, pick);
+            limit = __uint_as_float(st->pad[0] | pick[0]);
+        }
+        if (blockIdx.x == 0) {
+            if (threadIdx.x == 0) st->limit = limit;
+            for (int k = threadIdx.x; k < 2048; k += blockDim.x) hist1_to_zero[k] = 0;
+        }
+    } else if (f.use_trim == 1) {
+        limit = st->limit;
+    }
     double v[kSums];
 #pragma unroll
     for (int k = 0; k < kSums; ++k) v[k] = 0.0;
@@ -391,7 +546,7 @@ k_linearize_p2pl(const float4* __restrict__ src, const float4* __restrict__ src_
             v[29] = 1.0;
             w = 1.f;
             if (f.use_maxdist && !(dd <= f.outlier_max_d2)) w = 0.f;
-            if (f.use_trim && !(dd <= st->limit)) w = 0.f;
+            if (f.use_trim && !(dd <= limit)) w = 0.f;
             const float4 s = src[i];
             const float3 p = xf_point(T, s.x, s.y, s.z);
             const float4 nn = tgt_nrm[ps];
@@ -556,26 +711,46 @@ k_linearize_gicp(const float4* __restrict__ src, const float4* __restrict__ src_
     block_reduce_store(v, partials);
 }
 
-// fixed-order sum of the block partials -> out[kSums]
-__global__ void k_final_reduce(const double* __restrict__ partials, int n_blocks, double* __restrict__ out) {
-    __shared__ double sh[8][kSums];
-    const int comp = threadIdx.x & (kSums - 1), part = threadIdx.x / kSums;  // 256 threads = 8 parts x 32 comps
+// fixed-order sum of the block partials -> out[kSums]; optionally mirrored into mapped host memory
+// followed by a sequence word (the host polls it instead of synchronising the stream).
+__global__ void __launch_bounds__(1024)
+k_final_reduce(const double* __restrict__ partials, int n_blocks, double* __restrict__ out,
+               double* host_out, unsigned long long* host_seq, unsigned long long seq) {
+    __shared__ double sh[32][kSums];
+    const int comp = threadIdx.x & (kSums - 1), part = threadIdx.x / kSums;  // 32 parts x 32 comps
     double t = 0;
-    for (int b = part; b < n_blocks; b += 8) t += partials[(size_t)b * kSums + comp];
+    for (int b = part; b < n_blocks; b += 32) t += partials[(size_t)b * kSums + comp];
     sh[part][comp] = t;
     __syncthreads();
     if (threadIdx.x < kSums) {
         double s = 0;
-        for (int p = 0; p < 8; ++p) s += sh[p][threadIdx.x];
+        for (int p = 0; p < 32; ++p) s += sh[p][threadIdx.x];
         out[threadIdx.x] = s;
+        if (host_out) {
+            host_out[threadIdx.x] = s;
+            __threadfence_system();
+        }
+    }
+    __syncthreads();
+    if (host_seq && threadIdx.x == 0) {
+        __threadfence_system();
+        __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
-__global__ void k_ids_from_pos(const int* __restrict__ pos, const float4* __restrict__ tgt, int64_t n, int32_t* ids) {
+// results back into the caller's order: out[perm[i]] = value of slot i
+__global__ void k_ids_from_pos(const int* __restrict__ pos, const float4* __restrict__ tgt, int64_t n,
+                               const uint32_t* __restrict__ perm, int32_t* ids) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int p = pos[i];
-    ids[i] = p >= 0 ? (int32_t)__float_as_uint(tgt[p].w) : -1;
+    ids[perm ? (int64_t)perm[i] : i] = p >= 0 ? (int32_t)__float_as_uint(tgt[p].w) : -1;
+}
+__global__ void k_unpermute_f32(const float* __restrict__ in, int64_t n, const uint32_t* __restrict__ perm,
+                                float* __restrict__ out) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[perm ? (int64_t)perm[i] : i] = in[i];
 }
 
 // =================================================================================================
@@ -632,7 +807,12 @@ struct reg_handle {
     float T0[16];                  // T_refMean_readMean (row-major)
     // iteration buffers
     DevBuf i_pos, i_d2, i_w, i_hist, i_state, i_partials, i_sums, i_ids;
-    double* h_sums = nullptr;      // pinned
+    double* h_sums = nullptr;      // mapped pinned host memory: kSums doubles + one sequence word
+    double* d_hsums = nullptr;     // device view of h_sums
+    unsigned long long seq = 0;
+    DevBuf i_hint, s_keys, s_keys2, s_perm, s_perm2, s_tmp, i_tmpf;
+    const uint32_t* perm = nullptr;   // slot -> input index (null: identity)
+    int shift0 = 21;                  // low bit of the level-0 radix digit (19 when max_dist^2 < 2: bits 31,30 are 0)
     int n_blocks = 0;
     bool have_match = false;
 };
@@ -721,7 +901,13 @@ reg_status reg_create(const reg_params* p, reg_handle** out) {
     h->own_stream = true;
     (void)hipEventCreate(&h->ev0);
     (void)hipEventCreate(&h->ev1);
-    (void)hipHostMalloc((void**)&h->h_sums, kSums * sizeof(double), hipHostMallocDefault);
+    if (hipHostMalloc((void**)&h->h_sums, (kSums + 2) * sizeof(double), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&h->d_hsums, h->h_sums, 0) != hipSuccess) {
+        h->err = "hipHostMalloc(mapped) failed";
+        *out = h;
+        return REG_DEVICE_ERROR;
+    }
+    std::memset(h->h_sums, 0, (kSums + 2) * sizeof(double));
     *out = h;
     return REG_OK;
 }
@@ -732,7 +918,7 @@ void reg_destroy(reg_handle* h) {
                       &h->t_vals2, &h->t_pts, &h->t_nrm, &h->t_cov, &h->t_flags, &h->t_scan, &h->t_hash, &h->t_cells,
                       &h->t_tmp, &h->t_misc, &h->s_raw, &h->s_nrm_raw, &h->s_cov_raw, &h->s_xyz, &h->s_nrm, &h->s_cov,
                       &h->s_misc, &h->i_pos, &h->i_d2, &h->i_w, &h->i_hist, &h->i_state, &h->i_partials, &h->i_sums,
-                      &h->i_ids};
+                      &h->i_ids, &h->i_hint, &h->s_keys, &h->s_keys2, &h->s_perm, &h->s_perm2, &h->s_tmp, &h->i_tmpf};
     for (DevBuf* b : bufs) b->release();
     if (h->h_sums) (void)hipHostFree(h->h_sums);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -757,6 +943,17 @@ reg_status reg_set_stream(reg_handle* h, void* hip_stream) {
 static reg_status upload(reg_handle* h, DevBuf& dst, const float* src, size_t bytes, int on_device) {
     HIPCHK(h, dst.reserve(bytes));
     HIPCHK(h, hipMemcpyAsync(dst.p, src, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+    return REG_OK;
+}
+
+static reg_status device_centroid_sums(reg_handle* h, const float* d_xyz, int64_t stride, int64_t n, DevBuf& misc,
+                                       long long s[3]) {
+    HIPCHK(h, misc.reserve(256));
+    HIPCHK(h, hipMemsetAsync(misc.p, 0, 3 * sizeof(unsigned long long), h->stream));
+    const int blocks = std::min<int64_t>(1024, (n + 255) / 256);
+    k_centroid_sums<<<blocks, 256, 0, h->stream>>>(d_xyz, stride, n, misc.as<unsigned long long>());
+    HIPCHK(h, hipMemcpyAsync(s, misc.p, 3 * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return REG_OK;
 }
 
@@ -865,6 +1062,7 @@ static void set_levels(reg_handle* h, float c, float max_abs) {
     Grid& g = h->grid;
     const float md = h->prm.max_dist;
     g.max_d2 = std::isinf(md) ? INFINITY : md * md;
+    h->shift0 = (g.max_d2 < 2.0f) ? 19 : 21;
     int n = 0;
     float rho = 0.5f * c;
     const float abs_margin = 4e-7f * (1.0f + max_abs);
@@ -1057,6 +1255,7 @@ reg_status reg_set_source(reg_handle* h, const float* xyz, int64_t xyz_stride, c
     h->n_blocks = grid_for(n);
     HIPCHK(h, h->i_partials.reserve((size_t)h->n_blocks * kSums * 8));
     HIPCHK(h, h->i_sums.reserve(kSums * 8));
+    HIPCHK(h, h->i_hint.reserve((size_t)n));
     h->s_stride = xyz_stride;
     h->s_nstride = nrm_stride;
     return REG_OK;
@@ -1087,7 +1286,7 @@ static reg_status check_ready(reg_handle* h, bool need_prepared) {
 }
 
 // R2
-static reg_status prepare_rowmajor(reg_handle* h, const float* T_init_row) {
+static reg_status prepare_rowmajor(reg_handle* h, const float* T_init_row, const float* c_override = nullptr) {
     reg_status s = check_ready(h, false);
     if (s != REG_OK) return s;
     if (!m4_is_finite(T_init_row)) {
@@ -1098,8 +1297,12 @@ static reg_status prepare_rowmajor(reg_handle* h, const float* T_init_row) {
     std::memcpy(h->T_init, T_init_row, 64);
     const int64_t n = h->n;
     if (h->prm.cost == REG_COST_P2PL) {
-        s = device_centroid(h, h->s_raw.as<float>(), h->s_stride, n, h->s_misc, h->c_read);
-        if (s != REG_OK) return s;
+        if (c_override) {
+            std::memcpy(h->c_read, c_override, 12);
+        } else {
+            s = device_centroid(h, h->s_raw.as<float>(), h->s_stride, n, h->s_misc, h->c_read);
+            if (s != REG_OK) return s;
+        }
         float A[16], B[16], tmp[16];
         m4_identity(A);
         m4_identity(B);
@@ -1109,52 +1312,93 @@ static reg_status prepare_rowmajor(reg_handle* h, const float* T_init_row) {
         }
         m4_mul(A, T_init_row, tmp);
         m4_mul(tmp, B, h->T0);
-        k_prepare_source<<<grid_for(n), 256, 0, h->stream>>>(
-            h->s_raw.as<float>(), h->s_stride, h->has_snrm ? h->s_nrm_raw.as<float>() : nullptr, h->s_nstride, n,
-            h->c_read[0], h->c_read[1], h->c_read[2], make_xf(h->T0), 1, h->s_xyz.as<float4>(),
-            h->has_snrm ? h->s_nrm.as<float4>() : nullptr);
     } else {
         m4_identity(h->T0);
-        k_prepare_source<<<grid_for(n), 256, 0, h->stream>>>(h->s_raw.as<float>(), h->s_stride, nullptr, 3, n, 0.f, 0.f,
-                                                             0.f, make_xf(h->T0), 0, h->s_xyz.as<float4>(), nullptr);
-        k_pack_cov<<<grid_for(n), 256, 0, h->stream>>>(h->s_cov_raw.as<float>(), n, h->s_cov.as<float4>());
     }
+    const bool p2pl = h->prm.cost == REG_COST_P2PL;
+    const float* Tkey = p2pl ? h->T0 : T_init_row;
+    h->perm = nullptr;
+    if (h->prm.sort_source) {
+        const Grid& g = h->grid;
+        HIPCHK(h, h->s_keys.reserve((size_t)n * 4));
+        HIPCHK(h, h->s_keys2.reserve((size_t)n * 4));
+        HIPCHK(h, h->s_perm.reserve((size_t)n * 4));
+        HIPCHK(h, h->s_perm2.reserve((size_t)n * 4));
+        int shift = 0;
+        while (std::max(g.dimx, std::max(g.dimy, g.dimz)) / (float)(1 << shift) > 1024.f) ++shift;
+        k_source_keys<<<grid_for(n), 256, 0, h->stream>>>(h->s_raw.as<float>(), h->s_stride, n, h->c_read[0], h->c_read[1],
+                                                          h->c_read[2], make_xf(Tkey), p2pl ? 1 : 0, g.ox, g.oy, g.oz,
+                                                          g.inv_c, g.dimx, g.dimy, g.dimz, shift,
+                                                          h->s_keys.as<uint32_t>(), h->s_perm.as<uint32_t>());
+        size_t tb = 0;
+        HIPCHK(h, rocprim::radix_sort_pairs(nullptr, tb, h->s_keys.as<uint32_t>(), h->s_keys2.as<uint32_t>(),
+                                            h->s_perm.as<uint32_t>(), h->s_perm2.as<uint32_t>(), (size_t)n, 0, 30,
+                                            h->stream));
+        HIPCHK(h, h->s_tmp.reserve(tb));
+        HIPCHK(h, rocprim::radix_sort_pairs(h->s_tmp.p, tb, h->s_keys.as<uint32_t>(), h->s_keys2.as<uint32_t>(),
+                                            h->s_perm.as<uint32_t>(), h->s_perm2.as<uint32_t>(), (size_t)n, 0, 30,
+                                            h->stream));
+        h->perm = h->s_perm2.as<uint32_t>();
+    }
+    if (p2pl) {
+        k_prepare_source<<<grid_for(n), 256, 0, h->stream>>>(
+            h->s_raw.as<float>(), h->s_stride, h->has_snrm ? h->s_nrm_raw.as<float>() : nullptr, h->s_nstride, n,
+            h->c_read[0], h->c_read[1], h->c_read[2], make_xf(h->T0), 1, h->perm, h->s_xyz.as<float4>(),
+            h->has_snrm ? h->s_nrm.as<float4>() : nullptr);
+    } else {
+        k_prepare_source<<<grid_for(n), 256, 0, h->stream>>>(h->s_raw.as<float>(), h->s_stride, nullptr, 3, n, 0.f, 0.f,
+                                                             0.f, make_xf(h->T0), 0, h->perm, h->s_xyz.as<float4>(),
+                                                             nullptr);
+        k_pack_cov<<<grid_for(n), 256, 0, h->stream>>>(h->s_cov_raw.as<float>(), n, h->perm, h->s_cov.as<float4>());
+    }
+    HIPCHK(h, hipMemsetAsync(h->i_hint.p, 0, (size_t)n, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->i_hist.p, 0, 3 * 2048 * 4, h->stream));
     HIPCHK(h, hipGetLastError());
     h->prepared = true;
     h->have_match = false;
     return REG_OK;
 }
 
-// R3+R4 (+ level-0 histogram when the trimmed filter is active)
-static reg_status enqueue_match(reg_handle* h, const float* T_row) {
+// R3+R4 (+ level-0 histogram when the trimmed filter is active).  hist0 is zero on entry: reg_prepare
+// clears it and k_select_single re-clears it after use (zero_hist: callers that consume it otherwise).
+static reg_status enqueue_match(reg_handle* h, const float* T_row, bool zero_hist = false) {
     const bool trim = h->prm.cost == REG_COST_P2PL && h->prm.use_trimmed;
-    if (trim) HIPCHK(h, hipMemsetAsync(h->i_hist.p, 0, 3 * 2048 * 4, h->stream));
-    k_match<<<h->n_blocks, 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->n, make_xf(T_row), h->grid, h->i_pos.as<int>(),
-                                                h->i_d2.as<float>(), trim ? h->i_hist.as<uint32_t>() : nullptr);
+    if (trim && zero_hist) HIPCHK(h, hipMemsetAsync(h->i_hist.p, 0, 3 * 2048 * 4, h->stream));
+    const bool fused_hist = h->prm.match_variant == 3;
+    uint32_t* hist0 = (trim && fused_hist) ? h->i_hist.as<uint32_t>() : nullptr;
+    uint32_t* hist2 = trim ? h->i_hist.as<uint32_t>() + 4096 : nullptr;
+    if (h->prm.match_variant == 1) {
+        k_match<<<h->n_blocks, 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->n, make_xf(T_row), h->grid,
+                                                    h->i_pos.as<int>(), h->i_d2.as<float>(), hist0, hist2, h->shift0);
+    } else {
+        const int blocks = grid_for(h->n * kGroup);
+        k_match_g8<<<blocks, 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->n, make_xf(T_row), h->grid,
+                                                  h->i_pos.as<int>(), h->i_d2.as<float>(), hist0, hist2,
+                                                  h->prm.match_variant == 2 ? nullptr : h->i_hint.as<uint8_t>(), h->shift0);
+    }
     h->have_match = true;
     return REG_OK;
 }
 
-// exact k-th smallest finite d2 (3 radix passes), result in SelectState::limit on the device
+// exact k-th smallest finite d2: levels 1 and 2 here, the last level inside the linearize kernel.
+// Buffer hygiene without memset launches: this zeroes hist0, linearize zeroes hist1, match zeroes hist2.
 static reg_status enqueue_select(reg_handle* h) {
-    uint32_t* hist = h->i_hist.as<uint32_t>();
+    uint32_t* hist0 = h->i_hist.as<uint32_t>();
     SelectState* st = h->i_state.as<SelectState>();
-    HIPCHK(h, hipMemsetAsync(st, 0, sizeof(SelectState), h->stream));
+    const int hb = std::min(h->n_blocks, 128);
     const float ratio = h->prm.trim_ratio;
-    const int hb = std::min(h->n_blocks, 512);
-    k_select_pick<<<1, 256, 0, h->stream>>>(hist, 0, ratio, st);
-    k_select_hist<<<hb, 256, 0, h->stream>>>(h->i_d2.as<float>(), h->n, 1, st, hist + 2048);
-    k_select_pick<<<1, 256, 0, h->stream>>>(hist + 2048, 1, ratio, st);
-    k_select_hist<<<hb, 256, 0, h->stream>>>(h->i_d2.as<float>(), h->n, 2, st, hist + 4096);
-    k_select_pick<<<1, 256, 0, h->stream>>>(hist + 4096, 2, ratio, st);
+    if (h->prm.match_variant != 3)
+        k_hist_level0<<<hb, 256, 0, h->stream>>>(h->i_d2.as<float>(), h->n, h->shift0, hist0);
+    k_select_level<<<hb, 256, 0, h->stream>>>(h->i_d2.as<float>(), h->n, 1, h->shift0, ratio, hist0, hist0 + 2048, nullptr, st);
+    k_select_level<<<hb, 256, 0, h->stream>>>(h->i_d2.as<float>(), h->n, 2, h->shift0, ratio, hist0 + 2048, hist0 + 4096, hist0, st);
     return REG_OK;
 }
 
-static reg_status enqueue_linearize(reg_handle* h, const float* T_row, bool want_w) {
+static reg_status enqueue_linearize(reg_handle* h, const float* T_row, bool want_w, bool limit_from_state = false) {
     float* w = want_w ? h->i_w.as<float>() : nullptr;
     if (h->prm.cost == REG_COST_P2PL) {
         FilterCfg f;
-        f.use_trim = h->prm.use_trimmed;
+        f.use_trim = h->prm.use_trimmed ? (limit_from_state ? 1 : 2) : 0;
         f.use_normal = h->prm.use_surface_normal;
         f.use_maxdist = h->prm.use_max_dist_filter;
         f.cos_max_angle = std::cos(h->prm.max_normal_angle);  // cosf in T=float (OutlierFiltersImpl.cpp:229)
@@ -1163,18 +1407,43 @@ static reg_status enqueue_linearize(reg_handle* h, const float* T_row, bool want
         k_linearize_p2pl<<<h->n_blocks, 256, 0, h->stream>>>(
             h->s_xyz.as<float4>(), h->has_snrm ? h->s_nrm.as<float4>() : nullptr, h->n, make_xf(T_row),
             h->i_pos.as<int>(), h->i_d2.as<float>(), h->t_pts.as<float4>(), h->t_nrm.as<float4>(), f,
-            h->i_state.as<SelectState>(), w, h->i_partials.as<double>());
+            h->i_state.as<SelectState>(), h->i_hist.as<uint32_t>() + 4096, h->i_hist.as<uint32_t>() + 2048, h->shift0, w,
+            h->i_partials.as<double>());
     } else {
         k_linearize_gicp<<<h->n_blocks, 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->s_cov.as<float4>(), h->n,
                                                              make_xf(T_row), h->i_pos.as<int>(), h->i_d2.as<float>(),
                                                              h->t_pts.as<float4>(), h->t_cov.as<float4>(), w,
                                                              h->i_partials.as<double>());
     }
-    k_final_reduce<<<1, 256, 0, h->stream>>>(h->i_partials.as<double>(), h->n_blocks, h->i_sums.as<double>());
+    ++h->seq;
+    k_final_reduce<<<1, 1024, 0, h->stream>>>(h->i_partials.as<double>(), h->n_blocks, h->i_sums.as<double>(),
+                                              h->d_hsums, (unsigned long long*)(h->d_hsums + kSums), h->seq);
     return REG_OK;
 }
 
-// one full pass R3-R7 at T (row-major), sums -> h->h_sums (synchronises)
+// Wait until the final-reduce kernel of sequence h->seq has published its sums into the mapped host
+// buffer.  Polling the sequence word is ~10 us cheaper per iteration than hipStreamSynchronize; a stream
+// query every few thousand spins turns a device fault into an error instead of a hang.
+static reg_status wait_sums(reg_handle* h) {
+    volatile unsigned long long* seq = (volatile unsigned long long*)(h->h_sums + kSums);
+    for (unsigned spins = 0;; ++spins) {
+        if (__atomic_load_n((unsigned long long*)seq, __ATOMIC_ACQUIRE) == h->seq) return REG_OK;
+        if ((spins & 0x3fff) == 0x3fff) {
+            hipError_t e = hipStreamQuery(h->stream);
+            if (e == hipSuccess) {
+                if (__atomic_load_n((unsigned long long*)seq, __ATOMIC_ACQUIRE) == h->seq) return REG_OK;
+                h->err = "final reduce finished without publishing its sequence word";
+                return REG_DEVICE_ERROR;
+            }
+            if (e != hipErrorNotReady) {
+                h->err = std::string("device fault while waiting for the iteration: ") + hipGetErrorString(e);
+                return REG_DEVICE_ERROR;
+            }
+        }
+    }
+}
+
+// one full pass R3-R7 at T (row-major), sums -> h->h_sums (waits for the result)
 static reg_status iterate_once(reg_handle* h, const float* T_row, bool want_w) {
     reg_status s = enqueue_match(h, T_row);
     if (s != REG_OK) return s;
@@ -1184,10 +1453,7 @@ static reg_status iterate_once(reg_handle* h, const float* T_row, bool want_w) {
     }
     s = enqueue_linearize(h, T_row, want_w);
     if (s != REG_OK) return s;
-    HIPCHK(h, hipMemcpyAsync(h->h_sums, h->i_sums.p, kSums * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipGetLastError());
-    return REG_OK;
+    return wait_sums(h);
 }
 
 static void sums_to_system(const double* sums, bool p2pl, float* H, float* b) {
@@ -1199,6 +1465,24 @@ static void sums_to_system(const double* sums, bool p2pl, float* H, float* b) {
             H[6 * c + a] = v;
         }
     for (int a = 0; a < 6; ++a) b[a] = p2pl ? -(float)sums[21 + a] : (float)sums[21 + a];
+}
+
+// R10: T = T_refIn_refMean * T_iter * T_refMean_readMean * T_readIn_readMean^-1 (ICP.cpp:1345); GICP: T_iter itself
+static void compose_rowmajor(const reg_handle* h, const float* T_iter, float* Tout_row) {
+    if (h->prm.cost == REG_COST_P2PL) {
+        float A[16], B[16], t1[16], t2[16];
+        m4_identity(A);
+        m4_identity(B);
+        for (int k = 0; k < 3; ++k) {
+            A[4 * k + 3] = h->c_ref[k];
+            B[4 * k + 3] = -h->c_read[k];
+        }
+        m4_mul(A, T_iter, t1);
+        m4_mul(t1, h->T0, t2);
+        m4_mul(t2, B, Tout_row);
+    } else {
+        std::memcpy(Tout_row, T_iter, 64);
+    }
 }
 
 static void fill_result(reg_handle* h, const double* sums, reg_result* res) {
@@ -1335,21 +1619,8 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
     res->max_iter_reached = chk.max_iter_reached ? 1 : 0;
     fill_result(h, h->h_sums, res);
     float Tout_row[16];
-    if (p2pl) {
-        // R10: T = T_refIn_refMean * T_iter * T_refMean_readMean * T_readIn_readMean^-1 (ICP.cpp:1345)
-        float A[16], B[16], t1[16], t2[16];
-        m4_identity(A);
-        m4_identity(B);
-        for (int k = 0; k < 3; ++k) {
-            A[4 * k + 3] = h->c_ref[k];
-            B[4 * k + 3] = -h->c_read[k];
-        }
-        m4_mul(A, T_iter, t1);
-        m4_mul(t1, h->T0, t2);
-        m4_mul(t2, B, Tout_row);
-    } else {
-        std::memcpy(Tout_row, T_iter, 64);
-    }
+    compose_rowmajor(h, T_iter, Tout_row);
+    row_to_col(T_iter, res->T_iter_last);
     row_to_col(Tout_row, T_out);
     return REG_OK;
 }
@@ -1373,17 +1644,54 @@ reg_status reg_get_correspondences(reg_handle* h, int32_t* ids, float* d2, float
     const int64_t n = h->n;
     if (ids) {
         HIPCHK(h, h->i_ids.reserve((size_t)n * 4));
-        k_ids_from_pos<<<grid_for(n), 256, 0, h->stream>>>(h->i_pos.as<int>(), h->t_pts.as<float4>(), n,
+        k_ids_from_pos<<<grid_for(n), 256, 0, h->stream>>>(h->i_pos.as<int>(), h->t_pts.as<float4>(), n, h->perm,
                                                            h->i_ids.as<int32_t>());
         HIPCHK(h, hipMemcpyAsync(ids, h->i_ids.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
     }
-    if (d2) HIPCHK(h, hipMemcpyAsync(d2, h->i_d2.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
-    if (w) HIPCHK(h, hipMemcpyAsync(w, h->i_w.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, h->i_tmpf.reserve((size_t)n * 8));
+    if (d2) {
+        k_unpermute_f32<<<grid_for(n), 256, 0, h->stream>>>(h->i_d2.as<float>(), n, h->perm, h->i_tmpf.as<float>());
+        HIPCHK(h, hipMemcpyAsync(d2, h->i_tmpf.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    }
+    if (w) {
+        k_unpermute_f32<<<grid_for(n), 256, 0, h->stream>>>(h->i_w.as<float>(), n, h->perm, h->i_tmpf.as<float>() + n);
+        HIPCHK(h, hipMemcpyAsync(w, h->i_tmpf.as<float>() + n, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return REG_OK;
 }
 
-// ---- distributed halves -------------------------------------------------------------------------
+// ---- distributed halves ----
+
+reg_status reg_source_centroid_sums(reg_handle* h, int64_t sums[3]) {
+    reg_status s = check_ready(h, false);
+    if (s != REG_OK) return s;
+    if (!sums) return REG_BAD_ARGUMENT;
+    HIPCHK(h, hipSetDevice(h->prm.device));
+    long long t[3];
+    s = device_centroid_sums(h, h->s_raw.as<float>(), h->s_stride, h->n, h->s_misc, t);
+    if (s != REG_OK) return s;
+    for (int k = 0; k < 3; ++k) sums[k] = t[k];
+    return REG_OK;
+}
+
+reg_status reg_prepare_centroid(reg_handle* h, const float T_init[16], const float c_read[3]) {
+    if (!h || !T_init || !c_read) return REG_BAD_ARGUMENT;
+    float Tr[16];
+    col_to_row(T_init, Tr);
+    return prepare_rowmajor(h, Tr, c_read);
+}
+
+reg_status reg_compose(reg_handle* h, const float T_iter[16], float T_out[16]) {
+    reg_status s = check_ready(h, true);
+    if (s != REG_OK) return s;
+    if (!T_iter || !T_out) return REG_BAD_ARGUMENT;
+    float Tr[16], To[16];
+    col_to_row(T_iter, Tr);
+    compose_rowmajor(h, Tr, To);
+    row_to_col(To, T_out);
+    return REG_OK;
+}
 
 reg_status reg_match_local(reg_handle* h, const float T_iter[16]) {
     reg_status s = check_ready(h, true);
@@ -1391,7 +1699,7 @@ reg_status reg_match_local(reg_handle* h, const float T_iter[16]) {
     float Tr[16];
     col_to_row(T_iter, Tr);
     HIPCHK(h, hipSetDevice(h->prm.device));
-    s = enqueue_match(h, Tr);
+    s = enqueue_match(h, Tr, true);
     if (s != REG_OK) return s;
     HIPCHK(h, hipMemsetAsync(h->i_state.p, 0, sizeof(SelectState), h->stream));
     return REG_OK;
@@ -1402,16 +1710,10 @@ reg_status reg_trim_histogram(reg_handle* h, int level, uint32_t prefix, uint32_
     if (s != REG_OK) return s;
     if (level < 0 || level > 2 || !hist || !h->have_match) return REG_BAD_ARGUMENT;
     HIPCHK(h, hipSetDevice(h->prm.device));
+    // generic 11/11/10-bit split, independent of the single-GPU pipeline's histograms
     uint32_t* d_hist = h->i_hist.as<uint32_t>() + 2048 * level;
-    if (level > 0) {
-        SelectState st;
-        std::memset(&st, 0, sizeof(st));
-        st.prefix = prefix;
-        HIPCHK(h, hipMemcpyAsync(h->i_state.p, &st, sizeof(st), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipMemsetAsync(d_hist, 0, 2048 * 4, h->stream));
-        k_select_hist<<<std::min(h->n_blocks, 512), 256, 0, h->stream>>>(h->i_d2.as<float>(), h->n, level,
-                                                                         h->i_state.as<SelectState>(), d_hist);
-    }
+    HIPCHK(h, hipMemsetAsync(d_hist, 0, 2048 * 4, h->stream));
+    k_hist_prefix<<<std::min(h->n_blocks, 256), 256, 0, h->stream>>>(h->i_d2.as<float>(), h->n, level, prefix, d_hist);
     HIPCHK(h, hipMemcpyAsync(hist, d_hist, 2048 * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return REG_OK;
@@ -1429,11 +1731,10 @@ reg_status reg_reduce_local(reg_handle* h, const float T_iter[16], float trim_li
     st.limit = trim_limit;
     st.done = 1;
     HIPCHK(h, hipMemcpyAsync(h->i_state.p, &st, sizeof(st), hipMemcpyHostToDevice, h->stream));
-    s = enqueue_linearize(h, Tr, true);
+    s = enqueue_linearize(h, Tr, true, true);
     if (s != REG_OK) return s;
-    HIPCHK(h, hipMemcpyAsync(h->h_sums, h->i_sums.p, kSums * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipGetLastError());
+    s = wait_sums(h);
+    if (s != REG_OK) return s;
     std::memcpy(sums, h->h_sums, kSums * 8);
     return REG_OK;
 }
@@ -1470,6 +1771,49 @@ reg_status reg_solve_update(const reg_params* p, const double sums[32], const fl
         for (int i = 0; i < 16; ++i) Tr[i] = (float)Tn[i];
     }
     row_to_col(Tr, T_next);
+    return REG_OK;
+}
+
+// ---- measurement hook -------------------------------------------------------------------------------
+// Runs `reps` iterations' worth of kernels at T_iter and reports the average device time (ms, HIP events
+// on the handle's stream) of: [0] k_match, [1] the trimmed-quantile select passes, [2] k_linearize_* +
+// k_final_reduce.  Used by bench.py for the roofline object; not part of the registration semantics.
+reg_status reg_profile_kernels(reg_handle* h, const float T_iter[16], int reps, float ms[3]) {
+    reg_status s = check_ready(h, true);
+    if (s != REG_OK) return s;
+    if (!T_iter || !ms || reps <= 0) return REG_BAD_ARGUMENT;
+    float Tr[16];
+    col_to_row(T_iter, Tr);
+    HIPCHK(h, hipSetDevice(h->prm.device));
+    hipEvent_t e[4];
+    for (int i = 0; i < 4; ++i) HIPCHK(h, hipEventCreate(&e[i]));
+    double acc[3] = {0, 0, 0};
+    const bool trim = h->prm.cost == REG_COST_P2PL && h->prm.use_trimmed;
+    for (int r = 0; r < reps; ++r) {
+        if (trim) HIPCHK(h, hipMemsetAsync(h->i_hist.p, 0, 2048 * 4, h->stream));
+        HIPCHK(h, hipEventRecord(e[0], h->stream));
+        s = enqueue_match(h, Tr);
+        if (s != REG_OK) return s;
+        HIPCHK(h, hipEventRecord(e[1], h->stream));
+        if (trim) {
+            s = enqueue_select(h);
+            if (s != REG_OK) return s;
+        }
+        HIPCHK(h, hipEventRecord(e[2], h->stream));
+        s = enqueue_linearize(h, Tr, false);
+        if (s != REG_OK) return s;
+        HIPCHK(h, hipEventRecord(e[3], h->stream));
+        HIPCHK(h, hipEventSynchronize(e[3]));
+        for (int i = 0; i < 3; ++i) {
+            float t = 0;
+            (void)hipEventElapsedTime(&t, e[i], e[i + 1]);
+            acc[i] += t;
+        }
+    }
+    h->have_match = true;
+    for (int i = 0; i < 3; ++i) ms[i] = (float)(acc[i] / reps);
+    for (int i = 0; i < 4; ++i) (void)hipEventDestroy(e[i]);
+    HIPCHK(h, hipGetLastError());
     return REG_OK;
 }
 

@@ -163,4 +163,151 @@ __device__ __forceinline__ Best nearest(const Grid& g, float3 p) {
     return best;
 }
 
+
+// -------------------------------------------------------------------------------------------------
+// Cooperative search: kGroup (= 8) adjacent lanes share one query.  Work items of a box are spread
+// over the lanes of the group (level 0: the <= 2x2x2 bins, one bin per lane; wider boxes: one
+// (brick, y, z) row segment per lane), every lane scans its own contiguous run of sorted points,
+// and the group's best candidate is combined with three xor-shuffles.  All lanes of a group take the
+// same control flow, so divergence is limited to the 8 groups of a wave.
+// -------------------------------------------------------------------------------------------------
+constexpr int kGroup = 8;
+
+__device__ __forceinline__ void consider(const Grid& g, float3 p, const float4 t, int j, Best& best) {
+    const float dx = p.x - t.x, dy = p.y - t.y, dz = p.z - t.z;
+    float a = dx * dx;
+    float b = dy * dy;
+    float d2 = a + b;
+    a = dz * dz;
+    d2 = d2 + a;
+    const uint32_t idx = __float_as_uint(t.w);
+    if (d2 <= g.max_d2 && (d2 < best.d2 || (d2 == best.d2 && idx < best.idx))) {
+        best.d2 = d2;
+        best.idx = idx;
+        best.pos = j;
+    }
+}
+
+__device__ __forceinline__ void scan_run(const Grid& g, float3 p, uint32_t s, uint32_t e, Best& best) {
+    // two loads in flight per step; the clamped duplicate of the last point is harmless
+    for (uint32_t j = s; j < e; j += 2) {
+        const uint32_t j1 = min(j + 1, e - 1);
+        const float4 t0 = g.pts[j];
+        const float4 t1 = g.pts[j1];
+        consider(g, p, t0, (int)j, best);
+        consider(g, p, t1, (int)j1, best);
+    }
+}
+
+__device__ __forceinline__ Best group_min(Best b) {
+#pragma unroll
+    for (int m = 1; m < kGroup; m <<= 1) {
+        const float od2 = __shfl_xor(b.d2, m);
+        const uint32_t oidx = __shfl_xor(b.idx, m);
+        const int opos = __shfl_xor(b.pos, m);
+        if (od2 < b.d2 || (od2 == b.d2 && oidx < b.idx)) {
+            b.d2 = od2;
+            b.idx = oidx;
+            b.pos = opos;
+        }
+    }
+    return b;
+}
+
+// `sub` = lane index inside the group (0..7); `first_level` lets the caller skip radii that were too
+// small for this query in the previous iteration (any starting level is exact).  Returns the level at
+// which the search terminated through *level_out.
+//
+// A box is cut into row segments (one per (brick, y, z): a contiguous run of sorted points).  Phase 1:
+// each lane of the group looks up one segment (brick hash probe + two bin-start loads).  Phase 2: the
+// group scans every non-empty segment TOGETHER, lane k reading point s+k, s+k+8, ... -- consecutive
+// 16-byte records, i.e. one or two cache lines per group step instead of one line per lane.
+__device__ __forceinline__ Best nearest_group(const Grid& g, float3 p, int sub, int first_level, int* level_out) {
+    Best best;
+    best.d2 = INFINITY;
+    best.idx = 0xffffffffu;
+    best.pos = -1;
+    const int gbase = (int)(threadIdx.x & 63) & ~(kGroup - 1);  // first lane of this group in the wave
+    int l = min(first_level, g.n_levels - 1);
+    for (; l < g.n_levels; ++l) {
+        const float rb = g.rho_box[l];
+        const int lox = (int)fminf(fmaxf(bin_coord_f(p.x - rb, g.ox, g.inv_c), 0.f), g.dimx - 1.f);
+        const int loy = (int)fminf(fmaxf(bin_coord_f(p.y - rb, g.oy, g.inv_c), 0.f), g.dimy - 1.f);
+        const int loz = (int)fminf(fmaxf(bin_coord_f(p.z - rb, g.oz, g.inv_c), 0.f), g.dimz - 1.f);
+        const int hix = (int)fminf(fmaxf(bin_coord_f(p.x + rb, g.ox, g.inv_c), 0.f), g.dimx - 1.f);
+        const int hiy = (int)fminf(fmaxf(bin_coord_f(p.y + rb, g.oy, g.inv_c), 0.f), g.dimy - 1.f);
+        const int hiz = (int)fminf(fmaxf(bin_coord_f(p.z + rb, g.oz, g.inv_c), 0.f), g.dimz - 1.f);
+        const int ny = hiy - loy + 1, nz = hiz - loz + 1;
+        const int bx0 = lox >> kBrickLog2;
+        const int nbx = (hix >> kBrickLog2) - bx0 + 1;
+        const int nrow = nbx * ny;
+        const int total = nrow * nz;
+        for (int base = 0; base < total; base += kGroup) {
+            // phase 1: one segment per lane
+            uint32_t s = 0, e = 0;
+            const int t = base + sub;
+            if (t < total) {
+                const int iz = t / nrow, rem = t - iz * nrow;
+                const int iy = rem / nbx, ix = rem - iy * nbx;
+                const int bx = bx0 + ix, cy = loy + iy, cz = loz + iz;
+                const int bid = find_brick(g, brick_key((uint32_t)bx, (uint32_t)(cy >> kBrickLog2),
+                                                        (uint32_t)(cz >> kBrickLog2)));
+                if (bid >= 0) {
+                    const int x0 = max(lox, bx << kBrickLog2) & (kBrickDim - 1);
+                    const int x1 = min(hix, (bx << kBrickLog2) + kBrickDim - 1) & (kBrickDim - 1);
+                    const uint32_t* cs = g.cell_start + (size_t)bid * kBrickCells +
+                                         (((cz & (kBrickDim - 1)) << (2 * kBrickLog2)) |
+                                          ((cy & (kBrickDim - 1)) << kBrickLog2));
+                    s = cs[x0];
+                    e = cs[x1 + 1];
+                }
+            }
+            // phase 2: the group scans the CONCATENATION of its (up to 8) segments: flat candidate f belongs
+            // to the segment k with ex[k] <= f < ex[k+1]; lane `sub` takes f = sub, sub+8, ... and keeps
+            // kUnroll independent 16-byte loads in flight (the kernel is latency-bound, not bandwidth-bound).
+            const uint32_t cnt = e - s;
+            uint32_t incl = cnt;
+#pragma unroll
+            for (int o = 1; o < kGroup; o <<= 1) {
+                const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
+                if (sub >= o) incl += v;
+            }
+            const uint32_t total_pts = (uint32_t)__shfl((int)incl, gbase + kGroup - 1);
+            if (total_pts == 0) continue;
+            uint32_t ex[kGroup], st[kGroup];
+#pragma unroll
+            for (int k = 0; k < kGroup; ++k) {
+                ex[k] = (uint32_t)__shfl((int)(incl - cnt), gbase + k);
+                st[k] = (uint32_t)__shfl((int)s, gbase + k);
+            }
+            constexpr int kUnroll = 4;
+            for (uint32_t f0 = 0; f0 < total_pts; f0 += kUnroll * kGroup) {
+                float4 tv[kUnroll];
+                uint32_t jv[kUnroll];
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    const uint32_t f = min(f0 + (uint32_t)(u * kGroup + sub), total_pts - 1);  // clamp: duplicates are harmless
+                    uint32_t base_pt = st[0], base_f = 0;
+#pragma unroll
+                    for (int k = 1; k < kGroup; ++k)
+                        if (f >= ex[k]) {
+                            base_pt = st[k];
+                            base_f = ex[k];
+                        }
+                    jv[u] = base_pt + (f - base_f);
+                    tv[u] = g.pts[jv[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) consider(g, p, tv[u], (int)jv[u], best);
+            }
+        }
+        best = group_min(best);
+        const float r = g.rho[l];
+        const float r2 = r * r;
+        if (best.pos >= 0 && best.d2 <= r2) break;  // every point within rho was inside the box: exact
+    }
+    *level_out = min(l, g.n_levels - 1);
+    return best;
+}
+
 }  // namespace o3dreg

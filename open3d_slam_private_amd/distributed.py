@@ -1,0 +1,97 @@
+"""Point-partitioned registration across the GPUs of one node.
+
+The reading is split into contiguous slices, one per rank; the reference cloud and its voxel-bin
+table are replicated.  Per Gauss-Newton iteration every rank runs R3-R7 on its slice and the ranks
+exchange
+  * (TrimmedDist only) the exact global `ratio`-quantile of the squared match distances by a
+    3-level radix select: three all-reduces of a 2048-bin histogram (bits 31:21, 20:10, 9:0), and
+  * one all-reduce (sum) of 32 doubles {21 upper-triangular H, 6 b, error, #inliers, #matched, sum d2}.
+Every rank then solves the same 6x6 system redundantly (no broadcast).  `torch.distributed` is the
+transport (backend "nccl" == RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+
+The reference has no distributed path at all (single process); this module's
+contract is "same numbers as the single-rank path on the concatenated reading".
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+
+def select_from_hist(hist: np.ndarray, rank: int):
+    """Bin containing the element of 0-based `rank`, and the rank inside that bin."""
+    cum = np.cumsum(hist.astype(np.int64))
+    b = int(np.searchsorted(cum, rank, side="right"))
+    before = int(cum[b - 1]) if b > 0 else 0
+    return b, rank - before
+
+
+def trim_rank(n_finite: int, ratio: float) -> int:
+    """Index used by Matches::getDistsQuantile (Matches.cpp:82-86): size()*quantile in float, truncated;
+    quantile == 1 -> the maximum."""
+    if np.float32(ratio) == np.float32(1.0):
+        return max(n_finite - 1, 0)
+    r = int(np.float32(n_finite) * np.float32(ratio))
+    return min(r, max(n_finite - 1, 0))
+
+
+class DistributedRegistration:
+    """Drives one registration over all ranks of `group`.
+
+    `local` is this rank's slice backend and must provide
+        prepare_with_centroid / match_local(T) / trim_histogram(level, prefix) / reduce_local(T, limit)
+    (capi.Registration on the GPU box; an oracle-backed stand-in in the gloo CPU tests).
+    `solve_update(sums, T_iter) -> T_next` is the host-side R8/R9 step.
+    """
+
+    def __init__(self, local, solve_update, use_trimmed: bool, trim_ratio: float, fixed_iters: int = 20,
+                 dist=None, group=None, device=None):
+        self.local = local
+        self.solve_update = solve_update
+        self.use_trimmed = use_trimmed
+        self.trim_ratio = trim_ratio
+        self.fixed_iters = fixed_iters
+        self.dist = dist
+        self.group = group
+        self.device = device
+
+    def _allreduce(self, arr: np.ndarray) -> np.ndarray:
+        if self.dist is None or self.dist.get_world_size(self.group) == 1:
+            return arr
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(arr))
+        if self.device is not None:
+            t = t.to(self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t.cpu().numpy()
+
+    def global_trim_limit(self) -> float:
+        h0 = self._allreduce(self.local.trim_histogram(0, 0).astype(np.int64))
+        n_finite = int(h0.sum())
+        if n_finite == 0:
+            return math.inf
+        rank = trim_rank(n_finite, self.trim_ratio)
+        b0, rank = select_from_hist(h0, rank)
+        prefix = b0 << 21
+        h1 = self._allreduce(self.local.trim_histogram(1, prefix).astype(np.int64))
+        b1, rank = select_from_hist(h1, rank)
+        prefix |= b1 << 10
+        h2 = self._allreduce(self.local.trim_histogram(2, prefix).astype(np.int64))
+        b2, rank = select_from_hist(h2[:1024], rank)
+        prefix |= b2
+        return float(np.array([prefix], np.uint32).view(np.float32)[0])
+
+    def iterate(self, T_iter: np.ndarray):
+        """One Gauss-Newton iteration over all ranks.  Returns (T_next, global sums)."""
+        self.local.match_local(T_iter)
+        limit = self.global_trim_limit() if self.use_trimmed else math.inf
+        sums = self._allreduce(self.local.reduce_local(T_iter, limit))
+        return self.solve_update(sums, T_iter), sums
+
+    def run(self, T_iter0=None):
+        T = np.eye(4, dtype=np.float32) if T_iter0 is None else np.asarray(T_iter0, np.float32)
+        sums = None
+        for _ in range(self.fixed_iters):
+            T, sums = self.iterate(T)
+        return T, sums

@@ -37,6 +37,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -92,6 +93,11 @@ static void mat4_mul(const float A[16], const float B[16], float C[16]) {
             R[4 * i + j] = s + t;
         }
     memcpy(C, R, sizeof(R));
+}
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 static void mat4_identity(float T[16]) {
     memset(T, 0, 16 * sizeof(float));
@@ -678,6 +684,7 @@ typedef struct {
     float b_last[6];
     float T_iter[16];       /* in the centred frames */
     float T_refMean_readMean[16];
+    double loop_seconds;    /* wall time of the iteration loop only (kd-tree build excluded) */
 } orc_result;
 
 /* Full registration, R1-R10.  tgt_* must carry normals; src normals only needed for ORC_F_NORMAL.
@@ -743,6 +750,7 @@ ORC_API int orc_icp_p2pl(const float* tgt_xyz, int64_t tgt_stride, const float* 
     trans[0] = trans[1] = trans[2] = 0.f;
     hist = 1;
     int iterate = 1, count = 0, status = 0;
+    const double t_loop0 = now_s();
     while (iterate) {
         orc_knn(tree, rd, 3, n, T_iter, P->max_dist, ids, d2, P->n_threads);
         if (orc_weights(&P->filt, rdn, 3, tgt_nrm, tnrm_stride, T_iter, ids, d2, n, w, NULL) != 0) {
@@ -791,6 +799,7 @@ ORC_API int orc_icp_p2pl(const float* tgt_xyz, int64_t tgt_stride, const float* 
             res->max_iter_reached = 1;
         }
     }
+    res->loop_seconds = now_s() - t_loop0;
     res->iterations = count;
     res->status = status;
     memcpy(res->T_iter, T_iter, 64);
@@ -956,6 +965,7 @@ ORC_API int orc_icp_gicp(const float* tgt_xyz, int64_t tgt_stride, const float* 
     float Tf[16];
     int its = fixed_iters > 0 ? fixed_iters : max_iter;
     int status = 0;
+    const double t_loop0 = now_s();
     for (int it = 0; it < its; ++it) {
         for (int i = 0; i < 16; ++i) Tf[i] = (float)Td[i];
         orc_knn(tree, src_xyz, src_stride, n, Tf, max_dist, ids, d2, n_threads);
@@ -1003,6 +1013,7 @@ ORC_API int orc_icp_gicp(const float* tgt_xyz, int64_t tgt_stride, const float* 
             }
         }
     }
+    res->loop_seconds = now_s() - t_loop0;
     if (!res->converged && fixed_iters <= 0 && res->iterations >= max_iter) res->max_iter_reached = 1;
     res->status = status;
     for (int i = 0; i < 16; ++i) T_out[i] = (float)Td[i];

@@ -33,7 +33,7 @@ class Result(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32), ("max_iter_reached", C.c_int32),
                 ("status", C.c_int32), ("n_kept_last", C.c_int64), ("err_last", C.c_double),
                 ("A_last", C.c_float * 36), ("b_last", C.c_float * 6), ("T_iter", C.c_float * 16),
-                ("T_refMean_readMean", C.c_float * 16)]
+                ("T_refMean_readMean", C.c_float * 16), ("loop_seconds", C.c_double)]
 
 
 def build(force: bool = False) -> str:

@@ -145,3 +145,22 @@ def test_synth_shipped_chain(n_src, n_tgt):
     # and the registration actually recovers the synthetic motion
     dt, dr = synth.pose_error(T, sc.T_true)
     assert dt < 5e-3 and dr < 1e-3, (dt, dr)
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+def test_match_variants_agree_with_oracle(variant):
+    """All search kernels (8 lanes/point with and without level hints, 1 lane/point) are exact."""
+    sc = synth.make_scene(8000, 80000, seed=99)
+    p = capi.shipped_params()
+    p.match_variant = variant
+    reg = capi.Registration(p)
+    reg.set_target(sc.tgt_xyz, sc.tgt_nrm)
+    reg.set_source(sc.src_xyz, sc.src_nrm)
+    reg.prepare(np.eye(4))
+    _check_linearize(reg, sc.tgt_xyz, sc.tgt_nrm, sc.src_xyz, sc.src_nrm, 0.5, 0.9, 1.57)
+    # a second, different transform re-uses the level hints of the first call
+    T2 = np.eye(4, dtype=np.float32)
+    T2[:3, :3] = synth.rpy_to_R(0.004, -0.006, 0.03).astype(np.float32)
+    T2[:3, 3] = (0.1, -0.05, 0.02)
+    _check_linearize(reg, sc.tgt_xyz, sc.tgt_nrm, sc.src_xyz, sc.src_nrm, 0.5, 0.9, 1.57, T_iter=T2)
+    _check_linearize(reg, sc.tgt_xyz, sc.tgt_nrm, sc.src_xyz, sc.src_nrm, 0.5, 0.9, 1.57)
