@@ -11,22 +11,29 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
-#include <vector>
 
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define O3D_HD __host__ __device__
+#else
+#define O3D_HD
+#endif
+
+// NOTE: this header relies on being compiled with -ffp-contract=off (one rounding per fp32 operation).
 namespace o3dreg {
 
-inline void m4_identity(float* T) {
-    std::memset(T, 0, 16 * sizeof(float));
+O3D_HD inline void m4_identity(float* T) {
+    memset(T, 0, 16 * sizeof(float));
     T[0] = T[5] = T[10] = T[15] = 1.f;
 }
 
 // C = A*B with one rounding per operation, k = 0..3 in order (numeric contract NC3).
-inline void m4_mul(const float* A, const float* B, float* C) {
+O3D_HD inline void m4_mul(const float* A, const float* B, float* C) {
     float R[16];
     for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 4; ++j) {
-            volatile float s = A[4 * i] * B[j];
-            volatile float t = A[4 * i + 1] * B[4 + j];
+            float s = A[4 * i] * B[j];
+            float t = A[4 * i + 1] * B[4 + j];
             s = s + t;
             t = A[4 * i + 2] * B[8 + j];
             s = s + t;
@@ -34,19 +41,19 @@ inline void m4_mul(const float* A, const float* B, float* C) {
             s = s + t;
             R[4 * i + j] = s;
         }
-    std::memcpy(C, R, sizeof(R));
+    memcpy(C, R, sizeof(R));
 }
 
-inline void m4_transpose(const float* A, float* B) {
+O3D_HD inline void m4_transpose(const float* A, float* B) {
     float R[16];
     for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 4; ++j) R[4 * i + j] = A[4 * j + i];
-    std::memcpy(B, R, sizeof(R));
+    memcpy(B, R, sizeof(R));
 }
 
-inline bool m4_is_finite(const float* T) {
+O3D_HD inline bool m4_is_finite(const float* T) {
     for (int i = 0; i < 16; ++i)
-        if (!std::isfinite(T[i])) return false;
+        if (!(T[i] - T[i] == 0.0f)) return false;  // NaN or +-inf
     return true;
 }
 
@@ -55,7 +62,7 @@ inline bool m4_is_finite(const float* T) {
 // with the fp32 threshold size*eps_f32 of fullPivHouseholderQr::isInvertible) -> minimum-norm
 // solution through a Jacobi eigen-decomposition.  Returns the numerical rank.
 // ---------------------------------------------------------------------------------------------
-inline void jacobi_eig_sym(int n, double* A, double* V, double* lam) {
+O3D_HD inline void jacobi_eig_sym(int n, double* A, double* V, double* lam) {
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) V[i * n + j] = (i == j) ? 1.0 : 0.0;
     for (int sweep = 0; sweep < 64; ++sweep) {
@@ -66,10 +73,10 @@ inline void jacobi_eig_sym(int n, double* A, double* V, double* lam) {
         for (int p = 0; p < n; ++p)
             for (int q = p + 1; q < n; ++q) {
                 const double apq = A[p * n + q];
-                if (std::fabs(apq) < 1e-300) continue;
+                if (fabs(apq) < 1e-300) continue;
                 const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-                const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
                 for (int k = 0; k < n; ++k) {
                     const double akp = A[k * n + p], akq = A[k * n + q];
                     A[k * n + p] = c * akp - s * akq;
@@ -91,17 +98,17 @@ inline void jacobi_eig_sym(int n, double* A, double* V, double* lam) {
 }
 
 // rel_thr: eigenvalues <= rel_thr * max are treated as zero.
-inline int solve_sym6(const double* H, const double* g, double* x, double rel_thr) {
+O3D_HD inline int solve_sym6(const double* H, const double* g, double* x, double rel_thr) {
     double M[36], V[36], lam[6];
     for (int i = 0; i < 6; ++i)
         for (int j = 0; j < 6; ++j) M[6 * i + j] = 0.5 * (H[6 * i + j] + H[6 * j + i]);
     jacobi_eig_sym(6, M, V, lam);
     double lmax = 0;
-    for (int k = 0; k < 6; ++k) lmax = std::fmax(lmax, std::fabs(lam[k]));
+    for (int k = 0; k < 6; ++k) lmax = fmax(lmax, fabs(lam[k]));
     int rank = 0;
     for (int i = 0; i < 6; ++i) x[i] = 0;
     for (int k = 0; k < 6; ++k) {
-        if (!(std::fabs(lam[k]) > lmax * rel_thr)) continue;
+        if (!(fabs(lam[k]) > lmax * rel_thr)) continue;
         ++rank;
         double vb = 0;
         for (int i = 0; i < 6; ++i) vb += V[6 * i + k] * g[i];
@@ -111,7 +118,7 @@ inline int solve_sym6(const double* H, const double* g, double* x, double rel_th
     return rank;
 }
 
-inline int solve6_p2pl(const float* A, const float* b, float* x) {
+O3D_HD inline int solve6_p2pl(const float* A, const float* b, float* x) {
     double H[36], g[6], xd[6];
     for (int i = 0; i < 36; ++i) H[i] = A[i];
     for (int i = 0; i < 6; ++i) g[i] = b[i];
@@ -121,32 +128,32 @@ inline int solve6_p2pl(const float* A, const float* b, float* x) {
 }
 
 // x = [rx ry rz tx ty tz] -> row-major 4x4, fp32, one rounding per op (NC10).
-inline void x_to_T(const float* x, float* T) {
-    volatile float a = x[0] * x[0], b = x[1] * x[1], c = x[2] * x[2];
-    volatile float s = a + b;
+O3D_HD inline void x_to_T(const float* x, float* T) {
+    float a = x[0] * x[0], b = x[1] * x[1], c = x[2] * x[2];
+    float s = a + b;
     s = s + c;
-    const float nrm = std::sqrt((float)s);
-    const float angle = std::atan(nrm);
+    const float nrm = sqrt((float)s);
+    const float angle = atanf(nrm);
     float ax[3] = {x[0], x[1], x[2]};
-    const float w = std::fmax(std::fabs(x[0]), std::fmax(std::fabs(x[1]), std::fabs(x[2])));
+    const float w = fmax(fabs(x[0]), fmax(fabs(x[1]), fabs(x[2])));
     const float y0 = x[0] / w, y1 = x[1] / w, y2 = x[2] / w;
-    volatile float z = y0 * y0, z1 = y1 * y1;
+    float z = y0 * y0, z1 = y1 * y1;
     z = z + z1;
     z1 = y2 * y2;
     z = z + z1;
     if (z > 0.f) {
-        volatile float d = std::sqrt((float)z);
+        float d = sqrt((float)z);
         d = d * w;
         ax[0] = x[0] / d;
         ax[1] = x[1] / d;
         ax[2] = x[2] / d;
     }
-    const float sn = std::sin(angle), cs = std::cos(angle);
-    volatile float sa0 = sn * ax[0], sa1 = sn * ax[1], sa2 = sn * ax[2];
+    const float sn = sinf(angle), cs = cosf(angle);
+    float sa0 = sn * ax[0], sa1 = sn * ax[1], sa2 = sn * ax[2];
     const float c1 = 1.0f - cs;
-    volatile float ca0 = c1 * ax[0], ca1 = c1 * ax[1], ca2 = c1 * ax[2];
+    float ca0 = c1 * ax[0], ca1 = c1 * ax[1], ca2 = c1 * ax[2];
     float R[9];
-    volatile float t;
+    float t;
     t = ca0 * ax[1];
     R[1] = t - sa2;
     R[3] = t + sa2;
@@ -175,17 +182,17 @@ inline void x_to_T(const float* x, float* T) {
 }
 
 // SE(3) exponential (rotation first), fp64, row-major.
-inline void se3_exp(const double* d, double* T) {
+O3D_HD inline void se3_exp(const double* d, double* T) {
     const double w[3] = {d[0], d[1], d[2]}, v[3] = {d[3], d[4], d[5]};
-    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], th = std::sqrt(th2);
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], th = sqrt(th2);
     double A, B, C;
     if (th < 1e-10) {
         A = 1.0 - th2 / 6.0;
         B = 0.5 - th2 / 24.0;
         C = 1.0 / 6.0 - th2 / 120.0;
     } else {
-        A = std::sin(th) / th;
-        B = (1 - std::cos(th)) / th2;
+        A = sin(th) / th;
+        B = (1 - cos(th)) / th2;
         C = (1 - A) / th2;
     }
     const double K[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
@@ -196,7 +203,7 @@ inline void se3_exp(const double* d, double* T) {
             for (int k = 0; k < 3; ++k) s += K[3 * i + k] * K[3 * k + j];
             K2[3 * i + j] = s;
         }
-    std::memset(T, 0, 16 * sizeof(double));
+    memset(T, 0, 16 * sizeof(double));
     T[15] = 1;
     for (int i = 0; i < 3; ++i) {
         double t = 0;
@@ -211,11 +218,11 @@ inline void se3_exp(const double* d, double* T) {
 // ---------------------------------------------------------------------------------------------
 // Transformation checkers (TransformationCheckersImpl.cpp:57-158)
 // ---------------------------------------------------------------------------------------------
-inline void rot_to_quat(const float* T, float* q /* w x y z */) {
+O3D_HD inline void rot_to_quat(const float* T, float* q /* w x y z */) {
     const float m00 = T[0], m11 = T[5], m22 = T[10];
     const float tr = m00 + m11 + m22;
     if (tr > 0.f) {
-        float t = std::sqrt(tr + 1.0f);
+        float t = sqrt(tr + 1.0f);
         q[0] = 0.5f * t;
         t = 0.5f / t;
         q[1] = (T[9] - T[6]) * t;
@@ -226,7 +233,7 @@ inline void rot_to_quat(const float* T, float* q /* w x y z */) {
         if (m11 > m00) i = 1;
         if (m22 > T[5 * i]) i = 2;
         const int j = (i + 1) % 3, k = (j + 1) % 3;
-        float t = std::sqrt(T[5 * i] - T[5 * j] - T[5 * k] + 1.0f);
+        float t = sqrt(T[5 * i] - T[5 * j] - T[5 * k] + 1.0f);
         float v[3];
         v[i] = 0.5f * t;
         t = 0.5f / t;
@@ -239,50 +246,56 @@ inline void rot_to_quat(const float* T, float* q /* w x y z */) {
     }
 }
 
-inline float quat_angular_distance(const float* a, const float* b) {
+O3D_HD inline float quat_angular_distance(const float* a, const float* b) {
     const float bw = b[0], bx = -b[1], by = -b[2], bz = -b[3];
     const float w = a[0] * bw - a[1] * bx - a[2] * by - a[3] * bz;
     const float x = a[0] * bx + a[1] * bw + a[2] * bz - a[3] * by;
     const float y = a[0] * by + a[2] * bw + a[3] * bx - a[1] * bz;
     const float z = a[0] * bz + a[3] * bw + a[1] * by - a[2] * bx;
-    return 2.0f * std::atan2(std::sqrt(x * x + y * y + z * z), std::fabs(w));
+    return 2.0f * atan2f(sqrt(x * x + y * y + z * z), fabs(w));
 }
 
+constexpr int kCheckerHist = 16;   // smooth_len is clamped to kCheckerHist - 1
+
+// DifferentialTransformationChecker + CounterTransformationChecker state (fixed-size ring so the same
+// code runs inside the device-side update kernel).
 struct Checkers {
     int max_iter = 40;
     float min_diff_rot = 1e-3f, min_diff_trans = 1e-3f;
     int smooth_len = 3;
-    std::vector<float> quats, trans;
+    float quats[kCheckerHist][4];
+    float trans[kCheckerHist][3];
+    int n_hist = 0;        // total poses pushed (ring holds the last kCheckerHist)
     int count = 0;
     bool converged = false, max_iter_reached = false;
 
-    void init(const float* T) {
-        quats.clear();
-        trans.clear();
+    O3D_HD void init(const float* T) {
+        n_hist = 0;
         count = 0;
         converged = max_iter_reached = false;
+        if (smooth_len > kCheckerHist - 1) smooth_len = kCheckerHist - 1;
         push(T);
     }
-    void push(const float* T) {
-        float q[4];
-        rot_to_quat(T, q);
-        quats.insert(quats.end(), q, q + 4);
-        trans.push_back(T[3]);
-        trans.push_back(T[7]);
-        trans.push_back(T[11]);
+    O3D_HD void push(const float* T) {
+        const int slot = n_hist % kCheckerHist;
+        rot_to_quat(T, quats[slot]);
+        trans[slot][0] = T[3];
+        trans[slot][1] = T[7];
+        trans[slot][2] = T[11];
+        ++n_hist;
     }
     // returns `iterate`
-    bool check(const float* T) {
+    O3D_HD bool check(const float* T) {
         bool iterate = true;
         push(T);
-        const int hist = (int)trans.size() / 3;
-        if (smooth_len > 0 && hist > smooth_len) {
+        if (smooth_len > 0 && n_hist > smooth_len) {
             float cr = 0.f, ct = 0.f;
-            for (int i = hist - 1; i >= hist - smooth_len; --i) {
-                cr += std::fabs(quat_angular_distance(&quats[4 * i], &quats[4 * (i - 1)]));
-                const float dx = trans[3 * i] - trans[3 * (i - 1)], dy = trans[3 * i + 1] - trans[3 * (i - 1) + 1],
-                            dz = trans[3 * i + 2] - trans[3 * (i - 1) + 2];
-                ct += std::sqrt(dx * dx + dy * dy + dz * dz);
+            for (int i = n_hist - 1; i >= n_hist - smooth_len; --i) {
+                const int a = i % kCheckerHist, b = (i - 1) % kCheckerHist;
+                cr += fabsf(quat_angular_distance(quats[a], quats[b]));
+                const float dx = trans[a][0] - trans[b][0], dy = trans[a][1] - trans[b][1],
+                            dz = trans[a][2] - trans[b][2];
+                ct += sqrtf(dx * dx + dy * dy + dz * dz);
             }
             cr /= (float)smooth_len;
             ct /= (float)smooth_len;
@@ -299,5 +312,51 @@ struct Checkers {
         return iterate;
     }
 };
+
+// LDL^T solve of a symmetric 6x6 system in fp64 (no pivoting).  Returns false when a pivot falls below
+// rel_thr * (largest diagonal entry): the caller then uses the eigen-solve (minimum-norm) path.
+O3D_HD inline bool solve_ldlt6(const double* H, const double* g, double* x, double rel_thr) {
+    double L[36], d[6];
+    double dmax = 0;
+    for (int i = 0; i < 6; ++i) dmax = fmax(dmax, fabs(H[6 * i + i]));
+    if (!(dmax > 0)) return false;
+    for (int j = 0; j < 6; ++j) {
+        double dj = H[6 * j + j];
+        for (int k = 0; k < j; ++k) dj -= L[6 * j + k] * L[6 * j + k] * d[k];
+        if (!(dj > rel_thr * dmax)) return false;
+        d[j] = dj;
+        L[6 * j + j] = 1.0;
+        for (int i = j + 1; i < 6; ++i) {
+            double v = 0.5 * (H[6 * i + j] + H[6 * j + i]);
+            for (int k = 0; k < j; ++k) v -= L[6 * i + k] * L[6 * j + k] * d[k];
+            L[6 * i + j] = v / dj;
+        }
+    }
+    double y[6];
+    for (int i = 0; i < 6; ++i) {
+        double v = g[i];
+        for (int k = 0; k < i; ++k) v -= L[6 * i + k] * y[k];
+        y[i] = v;
+    }
+    for (int i = 0; i < 6; ++i) y[i] /= d[i];
+    for (int i = 5; i >= 0; --i) {
+        double v = y[i];
+        for (int k = i + 1; k < 6; ++k) v -= L[6 * k + i] * x[k];
+        x[i] = v;
+    }
+    return true;
+}
+
+// Point-to-plane step (R8): A x = b.  Well-conditioned -> LDL^T; otherwise the eigen-solve with the fp32
+// rank threshold (minimum-norm solution, PointToPlane.cpp:206-247).  Returns the numerical rank.
+O3D_HD inline int solve6_p2pl_fast(const float* A, const float* b, float* x) {
+    double H[36], g[6], xd[6];
+    for (int i = 0; i < 36; ++i) H[i] = A[i];
+    for (int i = 0; i < 6; ++i) g[i] = b[i];
+    int rank = 6;
+    if (!solve_ldlt6(H, g, xd, 1e-4)) rank = solve_sym6(H, g, xd, 6.0 * 1.1920929e-07);
+    for (int i = 0; i < 6; ++i) x[i] = (float)xd[i];
+    return rank;
+}
 
 }  // namespace o3dreg

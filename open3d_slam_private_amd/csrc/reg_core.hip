@@ -19,6 +19,40 @@
 
 using namespace o3dreg;
 
+// Iteration state living in device memory: the pose the kernels read, the checker history and the
+// termination flags.  The update kernel (last kernel of an iteration) is its only writer, so a whole
+// registration can be enqueued without a host round trip per Gauss-Newton iteration.
+struct IterState {
+    float T[16];          // T_iter, row-major (P2PL: centred frames; GICP: reading -> reference)
+    double Td[16];        // GICP: the same in double
+    Checkers chk;         // DifferentialTransformationChecker / CounterTransformationChecker state
+    int iterations;
+    int done;             // 1: the remaining enqueued kernels return immediately
+    int status;           // reg_status of the loop (REG_OK / REG_NO_CORRESPONDENCES)
+    int rank_last;
+    int cost;
+    int fixed_iters;
+    int max_iter;
+    int update;           // 0: reduce only (reg_linearize / distributed halves), 1: solve + update + check
+    float gicp_rot_eps, gicp_trans_eps;
+    double sums[kSums];
+};
+
+// What the update kernel mirrors into mapped host memory (the host polls `seq`).
+struct HostMirror {
+    double sums[kSums];
+    float T[16];
+    int iterations, done, status, rank_last, converged, max_iter_reached, pad0, pad1;
+    unsigned long long seq;
+};
+
+__device__ __forceinline__ Xf load_xf(const IterState* it) {
+    Xf x;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) x.m[k] = it->T[k];
+    return x;
+}
+
 // =================================================================================================
 // kernels: target preparation (R1)
 // =================================================================================================
@@ -235,9 +269,12 @@ __global__ void k_pack_cov(const float* __restrict__ cov, int64_t n, const uint3
 // Writes the sorted position of the match (-1 = none) and the squared distance (+inf = none), and the
 // level-0 radix histogram (top 11 bits) of the finite distances for the trimmed-quantile select.
 __global__ void __launch_bounds__(256)
-k_match(const float4* __restrict__ src, int64_t n, Xf T, Grid g, int* __restrict__ pos, float* __restrict__ d2,
-        uint32_t* __restrict__ hist0 /* 2048 or null */, uint32_t* __restrict__ hist2_to_zero, int shift0) {
+k_match(const float4* __restrict__ src, int64_t n, const IterState* __restrict__ it, Grid g, int* __restrict__ pos,
+        float* __restrict__ d2, uint32_t* __restrict__ hist0 /* 2048 or null */, uint32_t* __restrict__ hist2_to_zero,
+        int shift0) {
     __shared__ uint32_t sh[2048];
+    if (it->done) return;
+    const Xf T = load_xf(it);
     if (hist2_to_zero && blockIdx.x == 0)
         for (int k = threadIdx.x; k < 2048; k += blockDim.x) hist2_to_zero[k] = 0;
     if (hist0) {
@@ -263,10 +300,12 @@ k_match(const float4* __restrict__ src, int64_t n, Xf T, Grid g, int* __restrict
 // Cooperative variant: 8 lanes per reading point (32 points per 256-thread workgroup).
 // `hint` (one byte per point, may be null) carries the terminating level of the previous iteration.
 __global__ void __launch_bounds__(256)
-k_match_g8(const float4* __restrict__ src, int64_t n, Xf T, Grid g, int* __restrict__ pos, float* __restrict__ d2,
-           uint32_t* __restrict__ hist0 /* 2048 or null */, uint32_t* __restrict__ hist2_to_zero,
-           uint8_t* __restrict__ hint, int shift0) {
+k_match_g8(const float4* __restrict__ src, int64_t n, const IterState* __restrict__ it, Grid g, int* __restrict__ pos,
+           float* __restrict__ d2, uint32_t* __restrict__ hist0 /* 2048 or null */,
+           uint32_t* __restrict__ hist2_to_zero, uint8_t* __restrict__ hint, int shift0) {
     __shared__ uint32_t sh[2048];
+    if (it->done) return;
+    const Xf T = load_xf(it);
     if (hist2_to_zero && blockIdx.x == 0)
         for (int k = threadIdx.x; k < 2048; k += blockDim.x) hist2_to_zero[k] = 0;
     if (hist0) {
@@ -369,8 +408,10 @@ __device__ __forceinline__ uint32_t trim_rank(uint32_t total, float ratio) {
 // level = 2: pick level 1 from hist_prev (= hist1) using the state, histogram bits [9:0]; zero `to_zero`.
 __global__ void __launch_bounds__(256)
 k_select_level(const float* __restrict__ d2, int64_t n, int level, int shift0, float ratio, const uint32_t* __restrict__ hist_prev,
-               uint32_t* __restrict__ hist_out, uint32_t* __restrict__ to_zero, SelectState* st) {
+               uint32_t* __restrict__ hist_out, uint32_t* __restrict__ to_zero, SelectState* st,
+               const IterState* __restrict__ it) {
     __shared__ uint32_t sh[2048];
+    if (it->done) return;
     __shared__ uint32_t wave_tot[4];
     __shared__ uint32_t pick[3];
     for (int k = threadIdx.x; k < 2048; k += blockDim.x) sh[k] = 0;
@@ -424,8 +465,10 @@ k_select_level(const float* __restrict__ d2, int64_t n, int level, int shift0, f
 // Level-0 histogram of the single-GPU pipeline (digit = bits [shift0+10 : shift0]).  A separate pass with
 // few workgroups: folding it into the match kernel costs ~10^5 global atomics (~25-40 us on MI355X).
 __global__ void __launch_bounds__(256)
-k_hist_level0(const float* __restrict__ d2, int64_t n, int shift0, uint32_t* __restrict__ hist) {
+k_hist_level0(const float* __restrict__ d2, int64_t n, int shift0, uint32_t* __restrict__ hist,
+              const IterState* __restrict__ it) {
     __shared__ uint32_t sh[2048];
+    if (it->done) return;
     for (int k = threadIdx.x; k < 2048; k += blockDim.x) sh[k] = 0;
     __syncthreads();
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -512,11 +555,14 @@ __device__ __forceinline__ void block_reduce_store(double* vals /* kSums per thr
 // R5 + R6 + R7 (point-to-plane): weights, F = [p x n ; n], A += w F F^T, b -= w F (n.(p-q)).
 // Per-pair products in fp32 (as the reference computes them), summed in fp64 (numeric contract NC8).
 __global__ void __launch_bounds__(256)
-k_linearize_p2pl(const float4* __restrict__ src, const float4* __restrict__ src_nrm, int64_t n, Xf T,
+k_linearize_p2pl(const float4* __restrict__ src, const float4* __restrict__ src_nrm, int64_t n,
+                 const IterState* __restrict__ it,
                  const int* __restrict__ pos, const float* __restrict__ d2, const float4* __restrict__ tgt,
                  const float4* __restrict__ tgt_nrm, FilterCfg f, SelectState* __restrict__ st,
                  const uint32_t* __restrict__ hist2, uint32_t* __restrict__ hist1_to_zero, int shift0,
                  float* __restrict__ w_out, double* __restrict__ partials) {
+    if (it->done) return;
+    const Xf T = load_xf(it);
     // trimmed-quantile limit: last radix level, re-derived by every workgroup (f.use_trim == 2),
     // or taken from the state as given by the caller (f.use_trim == 1: distributed path)
     float limit = INFINITY;
@@ -607,9 +653,12 @@ k_linearize_p2pl(const float4* __restrict__ src, const float4* __restrict__ src_
 // GICP factor (north-star cost): r = q - T p, M = (Cq + R Cp R^T)^-1, J = [R skew(p), -R];
 // H += J^T M J, b += J^T M r, e += 0.5 r^T M r.  Per-point algebra in fp64 (inputs fp32).
 __global__ void __launch_bounds__(256)
-k_linearize_gicp(const float4* __restrict__ src, const float4* __restrict__ src_cov, int64_t n, Xf T,
+k_linearize_gicp(const float4* __restrict__ src, const float4* __restrict__ src_cov, int64_t n,
+                 const IterState* __restrict__ it,
                  const int* __restrict__ pos, const float* __restrict__ d2, const float4* __restrict__ tgt,
                  const float4* __restrict__ tgt_cov, float* __restrict__ w_out, double* __restrict__ partials) {
+    if (it->done) return;
+    const Xf T = load_xf(it);
     double v[kSums];
 #pragma unroll
     for (int k = 0; k < kSums; ++k) v[k] = 0.0;
@@ -711,12 +760,15 @@ k_linearize_gicp(const float4* __restrict__ src, const float4* __restrict__ src_
     block_reduce_store(v, partials);
 }
 
-// fixed-order sum of the block partials -> out[kSums]; optionally mirrored into mapped host memory
-// followed by a sequence word (the host polls it instead of synchronising the stream).
+// Last kernel of an iteration: fixed-order sum of the workgroup partials, then (it->update) R8 + R9 on
+// the device -- 6x6 solve in fp64, x -> 4x4, T_iter <- dT * T_iter, transformation checkers -- and a
+// mirror of the outcome into mapped host memory followed by a sequence word the host polls.
 __global__ void __launch_bounds__(1024)
-k_final_reduce(const double* __restrict__ partials, int n_blocks, double* __restrict__ out,
-               double* host_out, unsigned long long* host_seq, unsigned long long seq) {
+k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it, HostMirror* host,
+                unsigned long long seq) {
     __shared__ double sh[32][kSums];
+    __shared__ double tot[kSums];
+    if (it->done) return;
     const int comp = threadIdx.x & (kSums - 1), part = threadIdx.x / kSums;  // 32 parts x 32 comps
     double t = 0;
     for (int b = part; b < n_blocks; b += 32) t += partials[(size_t)b * kSums + comp];
@@ -725,17 +777,82 @@ k_final_reduce(const double* __restrict__ partials, int n_blocks, double* __rest
     if (threadIdx.x < kSums) {
         double s = 0;
         for (int p = 0; p < 32; ++p) s += sh[p][threadIdx.x];
-        out[threadIdx.x] = s;
-        if (host_out) {
-            host_out[threadIdx.x] = s;
-            __threadfence_system();
-        }
+        tot[threadIdx.x] = s;
+        it->sums[threadIdx.x] = s;
+        host->sums[threadIdx.x] = s;
     }
     __syncthreads();
-    if (host_seq && threadIdx.x == 0) {
-        __threadfence_system();
-        __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x != 0) return;
+    if (it->update) {
+        if (tot[28] == 0.0) {
+            it->status = REG_NO_CORRESPONDENCES;
+            it->done = 1;
+        } else if (it->cost == REG_COST_P2PL) {
+            float H[36], b6[6], x[6], dT[16], Tn[16];
+            int k = 0;
+            for (int a = 0; a < 6; ++a)
+                for (int c = a; c < 6; ++c) {
+                    const float v = (float)tot[k++];
+                    H[6 * a + c] = v;
+                    H[6 * c + a] = v;
+                }
+            for (int a = 0; a < 6; ++a) b6[a] = -(float)tot[21 + a];
+            it->rank_last = solve6_p2pl_fast(H, b6, x);
+            x_to_T(x, dT);
+            m4_mul(dT, it->T, Tn);  // T_iter = real * T_iter (ICP.cpp:1213-1215)
+            for (int i = 0; i < 16; ++i) it->T[i] = Tn[i];
+            it->iterations += 1;
+            bool iterate;
+            if (it->fixed_iters > 0)
+                iterate = it->iterations < it->fixed_iters;
+            else
+                iterate = it->chk.check(Tn);
+            if (!iterate) it->done = 1;
+        } else {
+            double Hd[36], g[6], dl[6], E[16], Tn[16];
+            int k = 0;
+            for (int a = 0; a < 6; ++a)
+                for (int c = a; c < 6; ++c) Hd[6 * a + c] = Hd[6 * c + a] = tot[k++];
+            for (int a = 0; a < 6; ++a) g[a] = -tot[21 + a];
+            int rank = 6;
+            if (!solve_ldlt6(Hd, g, dl, 1e-10)) rank = solve_sym6(Hd, g, dl, 1e-12);
+            it->rank_last = rank;
+            se3_exp(dl, E);
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j) {
+                    double v = 0;
+                    for (int kk = 0; kk < 4; ++kk) v += it->Td[4 * i + kk] * E[4 * kk + j];
+                    Tn[4 * i + j] = v;
+                }
+            for (int i = 0; i < 16; ++i) {
+                it->Td[i] = Tn[i];
+                it->T[i] = (float)Tn[i];
+            }
+            it->iterations += 1;
+            if (it->fixed_iters > 0) {
+                if (it->iterations >= it->fixed_iters) it->done = 1;
+            } else {
+                const double dr = sqrt(dl[0] * dl[0] + dl[1] * dl[1] + dl[2] * dl[2]);
+                const double dt = sqrt(dl[3] * dl[3] + dl[4] * dl[4] + dl[5] * dl[5]);
+                if (dr < (double)it->gicp_rot_eps && dt < (double)it->gicp_trans_eps) {
+                    it->chk.converged = true;
+                    it->done = 1;
+                } else if (it->iterations >= it->max_iter) {
+                    it->chk.max_iter_reached = true;
+                    it->done = 1;
+                }
+            }
+        }
     }
+    for (int i = 0; i < 16; ++i) host->T[i] = it->T[i];
+    host->iterations = it->iterations;
+    host->done = it->done;
+    host->status = it->status;
+    host->rank_last = it->rank_last;
+    host->converged = it->chk.converged ? 1 : 0;
+    host->max_iter_reached = it->chk.max_iter_reached ? 1 : 0;
+    __threadfence_system();
+    __hip_atomic_store(&host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // results back into the caller's order: out[perm[i]] = value of slot i
@@ -807,8 +924,10 @@ struct reg_handle {
     float T0[16];                  // T_refMean_readMean (row-major)
     // iteration buffers
     DevBuf i_pos, i_d2, i_w, i_hist, i_state, i_partials, i_sums, i_ids;
-    double* h_sums = nullptr;      // mapped pinned host memory: kSums doubles + one sequence word
-    double* d_hsums = nullptr;     // device view of h_sums
+    HostMirror* h_mirror = nullptr;   // mapped pinned host memory written by the update kernel
+    HostMirror* d_mirror = nullptr;   // device view of h_mirror
+    IterState* h_iter = nullptr;      // pinned staging copy of the iteration state
+    DevBuf i_iter;                    // IterState on the device
     unsigned long long seq = 0;
     DevBuf i_hint, s_keys, s_keys2, s_perm, s_perm2, s_tmp, i_tmpf;
     const uint32_t* perm = nullptr;   // slot -> input index (null: identity)
@@ -861,7 +980,7 @@ void reg_default_params(reg_params* p) {
     p->gicp_trans_eps = 1e-3f;
     p->cell_size = 0.f;
     p->device = 0;
-    p->sort_source = 0;
+    p->sort_source = 1;
 }
 
 void reg_shipped_params(reg_params* p) {
@@ -901,13 +1020,15 @@ reg_status reg_create(const reg_params* p, reg_handle** out) {
     h->own_stream = true;
     (void)hipEventCreate(&h->ev0);
     (void)hipEventCreate(&h->ev1);
-    if (hipHostMalloc((void**)&h->h_sums, (kSums + 2) * sizeof(double), hipHostMallocMapped) != hipSuccess ||
-        hipHostGetDevicePointer((void**)&h->d_hsums, h->h_sums, 0) != hipSuccess) {
-        h->err = "hipHostMalloc(mapped) failed";
+    if (hipHostMalloc((void**)&h->h_mirror, sizeof(HostMirror), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&h->d_mirror, h->h_mirror, 0) != hipSuccess ||
+        hipHostMalloc((void**)&h->h_iter, sizeof(IterState), hipHostMallocDefault) != hipSuccess ||
+        h->i_iter.reserve(sizeof(IterState)) != hipSuccess) {
+        h->err = "hipHostMalloc / hipMalloc of the iteration state failed";
         *out = h;
         return REG_DEVICE_ERROR;
     }
-    std::memset(h->h_sums, 0, (kSums + 2) * sizeof(double));
+    std::memset(h->h_mirror, 0, sizeof(HostMirror));
     *out = h;
     return REG_OK;
 }
@@ -918,9 +1039,10 @@ void reg_destroy(reg_handle* h) {
                       &h->t_vals2, &h->t_pts, &h->t_nrm, &h->t_cov, &h->t_flags, &h->t_scan, &h->t_hash, &h->t_cells,
                       &h->t_tmp, &h->t_misc, &h->s_raw, &h->s_nrm_raw, &h->s_cov_raw, &h->s_xyz, &h->s_nrm, &h->s_cov,
                       &h->s_misc, &h->i_pos, &h->i_d2, &h->i_w, &h->i_hist, &h->i_state, &h->i_partials, &h->i_sums,
-                      &h->i_ids, &h->i_hint, &h->s_keys, &h->s_keys2, &h->s_perm, &h->s_perm2, &h->s_tmp, &h->i_tmpf};
+                      &h->i_ids, &h->i_iter, &h->i_hint, &h->s_keys, &h->s_keys2, &h->s_perm, &h->s_perm2, &h->s_tmp, &h->i_tmpf};
     for (DevBuf* b : bufs) b->release();
-    if (h->h_sums) (void)hipHostFree(h->h_sums);
+    if (h->h_mirror) (void)hipHostFree(h->h_mirror);
+    if (h->h_iter) (void)hipHostFree(h->h_iter);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -1359,82 +1481,125 @@ static reg_status prepare_rowmajor(reg_handle* h, const float* T_init_row, const
     return REG_OK;
 }
 
-// R3+R4 (+ level-0 histogram when the trimmed filter is active).  hist0 is zero on entry: reg_prepare
-// clears it and k_select_single re-clears it after use (zero_hist: callers that consume it otherwise).
-static reg_status enqueue_match(reg_handle* h, const float* T_row, bool zero_hist = false) {
+// ---- iteration state ---------------------------------------------------------------------------------
+
+// (Re)initialise the device-side iteration state: pose T (row-major), mode and checker configuration.
+static reg_status init_iter_state(reg_handle* h, const float* T_row, int update) {
+    IterState* st = h->h_iter;
+    // the staging copy may still be in flight from a previous call on this stream
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::memset(st, 0, sizeof(IterState));
+    for (int i = 0; i < 16; ++i) {
+        st->T[i] = T_row[i];
+        st->Td[i] = (double)T_row[i];
+    }
+    st->chk = Checkers();
+    st->chk.max_iter = h->prm.max_iter;
+    st->chk.min_diff_rot = h->prm.min_diff_rot;
+    st->chk.min_diff_trans = h->prm.min_diff_trans;
+    st->chk.smooth_len = h->prm.smooth_len;
+    st->chk.init(T_row);
+    st->cost = h->prm.cost;
+    st->fixed_iters = h->prm.fixed_iters;
+    st->max_iter = h->prm.max_iter;
+    st->update = update;
+    st->gicp_rot_eps = h->prm.gicp_rot_eps;
+    st->gicp_trans_eps = h->prm.gicp_trans_eps;
+    HIPCHK(h, hipMemcpyAsync(h->i_iter.p, st, sizeof(IterState), hipMemcpyHostToDevice, h->stream));
+    return REG_OK;
+}
+
+// R3+R4.  Buffer hygiene of the trimmed-quantile histograms needs no memset launches: the match kernel
+// zeroes hist2, the level-2 select kernel zeroes hist0, the linearize kernel zeroes hist1.
+static reg_status enqueue_match(reg_handle* h, bool zero_hist = false) {
     const bool trim = h->prm.cost == REG_COST_P2PL && h->prm.use_trimmed;
     if (trim && zero_hist) HIPCHK(h, hipMemsetAsync(h->i_hist.p, 0, 3 * 2048 * 4, h->stream));
     const bool fused_hist = h->prm.match_variant == 3;
     uint32_t* hist0 = (trim && fused_hist) ? h->i_hist.as<uint32_t>() : nullptr;
     uint32_t* hist2 = trim ? h->i_hist.as<uint32_t>() + 4096 : nullptr;
+    const IterState* it = h->i_iter.as<IterState>();
     if (h->prm.match_variant == 1) {
-        k_match<<<h->n_blocks, 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->n, make_xf(T_row), h->grid,
-                                                    h->i_pos.as<int>(), h->i_d2.as<float>(), hist0, hist2, h->shift0);
+        k_match<<<h->n_blocks, 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->n, it, h->grid, h->i_pos.as<int>(),
+                                                    h->i_d2.as<float>(), hist0, hist2, h->shift0);
     } else {
         const int blocks = grid_for(h->n * kGroup);
-        k_match_g8<<<blocks, 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->n, make_xf(T_row), h->grid,
-                                                  h->i_pos.as<int>(), h->i_d2.as<float>(), hist0, hist2,
-                                                  h->prm.match_variant == 2 ? nullptr : h->i_hint.as<uint8_t>(), h->shift0);
+        k_match_g8<<<blocks, 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->n, it, h->grid, h->i_pos.as<int>(),
+                                                  h->i_d2.as<float>(), hist0, hist2,
+                                                  h->prm.match_variant == 2 ? nullptr : h->i_hint.as<uint8_t>(),
+                                                  h->shift0);
     }
     h->have_match = true;
     return REG_OK;
 }
 
-// exact k-th smallest finite d2: levels 1 and 2 here, the last level inside the linearize kernel.
-// Buffer hygiene without memset launches: this zeroes hist0, linearize zeroes hist1, match zeroes hist2.
+// exact k-th smallest finite d2: level 0 and 1 histograms here, the last level inside the linearize kernel
 static reg_status enqueue_select(reg_handle* h) {
     uint32_t* hist0 = h->i_hist.as<uint32_t>();
     SelectState* st = h->i_state.as<SelectState>();
+    const IterState* it = h->i_iter.as<IterState>();
     const int hb = std::min(h->n_blocks, 128);
     const float ratio = h->prm.trim_ratio;
     if (h->prm.match_variant != 3)
-        k_hist_level0<<<hb, 256, 0, h->stream>>>(h->i_d2.as<float>(), h->n, h->shift0, hist0);
-    k_select_level<<<hb, 256, 0, h->stream>>>(h->i_d2.as<float>(), h->n, 1, h->shift0, ratio, hist0, hist0 + 2048, nullptr, st);
-    k_select_level<<<hb, 256, 0, h->stream>>>(h->i_d2.as<float>(), h->n, 2, h->shift0, ratio, hist0 + 2048, hist0 + 4096, hist0, st);
+        k_hist_level0<<<hb, 256, 0, h->stream>>>(h->i_d2.as<float>(), h->n, h->shift0, hist0, it);
+    k_select_level<<<hb, 256, 0, h->stream>>>(h->i_d2.as<float>(), h->n, 1, h->shift0, ratio, hist0, hist0 + 2048,
+                                              nullptr, st, it);
+    k_select_level<<<hb, 256, 0, h->stream>>>(h->i_d2.as<float>(), h->n, 2, h->shift0, ratio, hist0 + 2048,
+                                              hist0 + 4096, hist0, st, it);
     return REG_OK;
 }
 
-static reg_status enqueue_linearize(reg_handle* h, const float* T_row, bool want_w, bool limit_from_state = false) {
+static reg_status enqueue_linearize(reg_handle* h, bool want_w, bool limit_from_state = false) {
     float* w = want_w ? h->i_w.as<float>() : nullptr;
+    const IterState* it = h->i_iter.as<IterState>();
     if (h->prm.cost == REG_COST_P2PL) {
         FilterCfg f;
         f.use_trim = h->prm.use_trimmed ? (limit_from_state ? 1 : 2) : 0;
         f.use_normal = h->prm.use_surface_normal;
         f.use_maxdist = h->prm.use_max_dist_filter;
         f.cos_max_angle = std::cos(h->prm.max_normal_angle);  // cosf in T=float (OutlierFiltersImpl.cpp:229)
-        volatile float md = h->prm.outlier_max_dist;
+        const float md = h->prm.outlier_max_dist;
         f.outlier_max_d2 = md * md;
         k_linearize_p2pl<<<h->n_blocks, 256, 0, h->stream>>>(
-            h->s_xyz.as<float4>(), h->has_snrm ? h->s_nrm.as<float4>() : nullptr, h->n, make_xf(T_row),
-            h->i_pos.as<int>(), h->i_d2.as<float>(), h->t_pts.as<float4>(), h->t_nrm.as<float4>(), f,
-            h->i_state.as<SelectState>(), h->i_hist.as<uint32_t>() + 4096, h->i_hist.as<uint32_t>() + 2048, h->shift0, w,
+            h->s_xyz.as<float4>(), h->has_snrm ? h->s_nrm.as<float4>() : nullptr, h->n, it, h->i_pos.as<int>(),
+            h->i_d2.as<float>(), h->t_pts.as<float4>(), h->t_nrm.as<float4>(), f, h->i_state.as<SelectState>(),
+            h->i_hist.as<uint32_t>() + 4096, h->i_hist.as<uint32_t>() + 2048, h->shift0, w,
             h->i_partials.as<double>());
     } else {
-        k_linearize_gicp<<<h->n_blocks, 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->s_cov.as<float4>(), h->n,
-                                                             make_xf(T_row), h->i_pos.as<int>(), h->i_d2.as<float>(),
+        k_linearize_gicp<<<h->n_blocks, 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->s_cov.as<float4>(), h->n, it,
+                                                             h->i_pos.as<int>(), h->i_d2.as<float>(),
                                                              h->t_pts.as<float4>(), h->t_cov.as<float4>(), w,
                                                              h->i_partials.as<double>());
     }
     ++h->seq;
-    k_final_reduce<<<1, 1024, 0, h->stream>>>(h->i_partials.as<double>(), h->n_blocks, h->i_sums.as<double>(),
-                                              h->d_hsums, (unsigned long long*)(h->d_hsums + kSums), h->seq);
+    k_reduce_update<<<1, 1024, 0, h->stream>>>(h->i_partials.as<double>(), h->n_blocks, h->i_iter.as<IterState>(),
+                                               h->d_mirror, h->seq);
     return REG_OK;
 }
 
-// Wait until the final-reduce kernel of sequence h->seq has published its sums into the mapped host
-// buffer.  Polling the sequence word is ~10 us cheaper per iteration than hipStreamSynchronize; a stream
-// query every few thousand spins turns a device fault into an error instead of a hang.
-static reg_status wait_sums(reg_handle* h) {
-    volatile unsigned long long* seq = (volatile unsigned long long*)(h->h_sums + kSums);
+// One Gauss-Newton iteration worth of kernels (R3-R9), nothing waits on the host.
+static reg_status enqueue_iteration(reg_handle* h, bool want_w) {
+    reg_status s = enqueue_match(h);
+    if (s != REG_OK) return s;
+    if (h->prm.cost == REG_COST_P2PL && h->prm.use_trimmed) {
+        s = enqueue_select(h);
+        if (s != REG_OK) return s;
+    }
+    return enqueue_linearize(h, want_w);
+}
+
+static inline unsigned long long mirror_seq(const reg_handle* h) {
+    return __atomic_load_n(&h->h_mirror->seq, __ATOMIC_ACQUIRE);
+}
+
+// Wait until the update kernel with sequence number `seq` (or a later one) has published its mirror.
+// Polling the mapped word is ~10 us cheaper per wait than hipStreamSynchronize; a stream query every few
+// thousand spins turns a device fault (or an early `done`) into a return instead of a hang.
+static reg_status wait_seq(reg_handle* h, unsigned long long seq) {
     for (unsigned spins = 0;; ++spins) {
-        if (__atomic_load_n((unsigned long long*)seq, __ATOMIC_ACQUIRE) == h->seq) return REG_OK;
+        if (mirror_seq(h) >= seq) return REG_OK;
         if ((spins & 0x3fff) == 0x3fff) {
             hipError_t e = hipStreamQuery(h->stream);
-            if (e == hipSuccess) {
-                if (__atomic_load_n((unsigned long long*)seq, __ATOMIC_ACQUIRE) == h->seq) return REG_OK;
-                h->err = "final reduce finished without publishing its sequence word";
-                return REG_DEVICE_ERROR;
-            }
+            if (e == hipSuccess) return REG_OK;  // everything enqueued has run (later iterations were no-ops)
             if (e != hipErrorNotReady) {
                 h->err = std::string("device fault while waiting for the iteration: ") + hipGetErrorString(e);
                 return REG_DEVICE_ERROR;
@@ -1443,17 +1608,16 @@ static reg_status wait_sums(reg_handle* h) {
     }
 }
 
-// one full pass R3-R7 at T (row-major), sums -> h->h_sums (waits for the result)
+// one full pass R3-R7 at T (row-major) without pose update; sums -> h->h_mirror->sums
 static reg_status iterate_once(reg_handle* h, const float* T_row, bool want_w) {
-    reg_status s = enqueue_match(h, T_row);
+    reg_status s = init_iter_state(h, T_row, 0);
     if (s != REG_OK) return s;
-    if (h->prm.cost == REG_COST_P2PL && h->prm.use_trimmed) {
-        s = enqueue_select(h);
-        if (s != REG_OK) return s;
-    }
-    s = enqueue_linearize(h, T_row, want_w);
+    s = enqueue_iteration(h, want_w);
     if (s != REG_OK) return s;
-    return wait_sums(h);
+    s = wait_seq(h, h->seq);
+    if (s != REG_OK) return s;
+    HIPCHK(h, hipGetLastError());
+    return REG_OK;
 }
 
 static void sums_to_system(const double* sums, bool p2pl, float* H, float* b) {
@@ -1515,16 +1679,21 @@ reg_status reg_linearize(reg_handle* h, const float T_iter[16], float H[36], flo
     HIPCHK(h, hipSetDevice(h->prm.device));
     s = iterate_once(h, Tr, true);
     if (s != REG_OK) return s;
-    if (H && b) sums_to_system(h->h_sums, h->prm.cost == REG_COST_P2PL, H, b);
-    if (err) *err = h->h_sums[27];
-    if (n_inliers) *n_inliers = (int64_t)llround(h->h_sums[28]);
-    if (h->h_sums[28] == 0.0) {
+    const double* sums = h->h_mirror->sums;
+    if (H && b) sums_to_system(sums, h->prm.cost == REG_COST_P2PL, H, b);
+    if (err) *err = sums[27];
+    if (n_inliers) *n_inliers = (int64_t)llround(sums[28]);
+    if (sums[28] == 0.0) {
         h->err = "ErrorMinimizer: no point to minimize";
         return REG_NO_CORRESPONDENCES;
     }
     return REG_OK;
 }
 
+// == ICP::compute on the prepared reading.  The whole while(iterate) loop (ICP.cpp:1027-1311) runs on the
+// device; the host only keeps the queue fed.  fixed_iters > 0: every iteration is enqueued at once.
+// Checker mode: the host stays at most kAhead iterations ahead of what it has seen complete, so at most
+// kAhead enqueued iterations turn into no-ops after convergence.
 reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], reg_result* res) {
     if (!h || !T_init || !T_out) return REG_BAD_ARGUMENT;
     reg_result local;
@@ -1536,89 +1705,52 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
     reg_status s = prepare_rowmajor(h, Ti);
     if (s != REG_OK) return s;
     const bool p2pl = h->prm.cost == REG_COST_P2PL;
-    const int fixed = h->prm.fixed_iters;
+    float T_start[16];
+    if (p2pl)
+        m4_identity(T_start);
+    else
+        std::memcpy(T_start, Ti, 64);
+    s = init_iter_state(h, T_start, 1);
+    if (s != REG_OK) return s;
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    float T_iter[16];
-    double Td[16];
-    if (p2pl) {
-        m4_identity(T_iter);
-    } else {
-        std::memcpy(T_iter, Ti, 64);
-        for (int i = 0; i < 16; ++i) Td[i] = Ti[i];
-    }
-    Checkers chk;
-    chk.max_iter = h->prm.max_iter;
-    chk.min_diff_rot = h->prm.min_diff_rot;
-    chk.min_diff_trans = h->prm.min_diff_trans;
-    chk.smooth_len = h->prm.smooth_len;
-    chk.init(T_iter);
-    bool iterate = true;
-    int count = 0;
-    while (iterate) {
-        s = iterate_once(h, T_iter, false);
+    const unsigned long long seq0 = h->seq;
+    const int fixed = h->prm.fixed_iters;
+    const int limit = fixed > 0 ? fixed : h->prm.max_iter;
+    constexpr int kAhead = 2;
+    int enq = 0;
+    const HostMirror* mir = h->h_mirror;
+    for (;;) {
+        const unsigned long long seen_seq = mirror_seq(h);
+        const int seen = seen_seq > seq0 ? (int)(seen_seq - seq0) : 0;
+        const bool done = seen > 0 && mir->done;
+        if (done || (seen >= limit)) break;
+        if (enq < limit && (fixed > 0 || enq - seen < kAhead)) {
+            s = enqueue_iteration(h, false);
+            if (s != REG_OK) return s;
+            ++enq;
+            continue;
+        }
+        if (enq == seen) break;  // nothing in flight and nothing left to enqueue
+        s = wait_seq(h, seq0 + (unsigned long long)seen + 1);
         if (s != REG_OK) return s;
-        const double* sums = h->h_sums;
-        if (sums[28] == 0.0) {
-            h->err = sums[29] == 0.0 ? "No matches available for computing distance quantiles"
-                                     : "ErrorMinimizer: no point to minimize";
-            res->iterations = count;
-            fill_result(h, sums, res);
-            return REG_NO_CORRESPONDENCES;
-        }
-        float H[36], b[6];
-        sums_to_system(sums, p2pl, H, b);
-        if (p2pl) {
-            float x[6], dT[16];
-            res->rank_last = solve6_p2pl(H, b, x);
-            x_to_T(x, dT);
-            m4_mul(dT, T_iter, T_iter);  // T_iter = real * T_iter (ICP.cpp:1213-1215)
-            ++count;
-            if (fixed > 0)
-                iterate = count < fixed;
-            else
-                iterate = chk.check(T_iter);
-        } else {
-            double Hd[36], g[6], dl[6], E[16], Tn[16];
-            int k = 0;
-            for (int a = 0; a < 6; ++a)
-                for (int c = a; c < 6; ++c) {
-                    Hd[6 * a + c] = Hd[6 * c + a] = sums[k++];
-                }
-            for (int a = 0; a < 6; ++a) g[a] = -sums[21 + a];
-            res->rank_last = solve_sym6(Hd, g, dl, 1e-12);
-            se3_exp(dl, E);
-            for (int i = 0; i < 4; ++i)
-                for (int j = 0; j < 4; ++j) {
-                    double t = 0;
-                    for (int kk = 0; kk < 4; ++kk) t += Td[4 * i + kk] * E[4 * kk + j];
-                    Tn[4 * i + j] = t;
-                }
-            std::memcpy(Td, Tn, sizeof(Td));
-            for (int i = 0; i < 16; ++i) T_iter[i] = (float)Td[i];
-            ++count;
-            if (fixed > 0) {
-                iterate = count < fixed;
-            } else {
-                const double dr = std::sqrt(dl[0] * dl[0] + dl[1] * dl[1] + dl[2] * dl[2]);
-                const double dt = std::sqrt(dl[3] * dl[3] + dl[4] * dl[4] + dl[5] * dl[5]);
-                if (dr < h->prm.gicp_rot_eps && dt < h->prm.gicp_trans_eps) {
-                    chk.converged = true;
-                    iterate = false;
-                } else if (count >= h->prm.max_iter) {
-                    chk.max_iter_reached = true;
-                    iterate = false;
-                }
-            }
-        }
+        if (mirror_seq(h) < seq0 + (unsigned long long)seen + 1) break;  // stream drained: remaining work was no-ops
     }
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipEventSynchronize(h->ev1));
+    HIPCHK(h, hipGetLastError());
     (void)hipEventElapsedTime(&res->loop_ms, h->ev0, h->ev1);
-    res->iterations = count;
-    res->converged = chk.converged ? 1 : 0;
-    res->max_iter_reached = chk.max_iter_reached ? 1 : 0;
-    fill_result(h, h->h_sums, res);
-    float Tout_row[16];
+    res->iterations = mir->iterations;
+    res->converged = mir->converged;
+    res->max_iter_reached = mir->max_iter_reached;
+    res->rank_last = mir->rank_last;
+    fill_result(h, mir->sums, res);
+    if (mir->status != REG_OK) {
+        h->err = mir->sums[29] == 0.0 ? "No matches available for computing distance quantiles"
+                                      : "ErrorMinimizer: no point to minimize";
+        return (reg_status)mir->status;
+    }
+    float T_iter[16], Tout_row[16];
+    std::memcpy(T_iter, mir->T, 64);
     compose_rowmajor(h, T_iter, Tout_row);
     row_to_col(T_iter, res->T_iter_last);
     row_to_col(Tout_row, T_out);
@@ -1699,7 +1831,9 @@ reg_status reg_match_local(reg_handle* h, const float T_iter[16]) {
     float Tr[16];
     col_to_row(T_iter, Tr);
     HIPCHK(h, hipSetDevice(h->prm.device));
-    s = enqueue_match(h, Tr, true);
+    s = init_iter_state(h, Tr, 0);
+    if (s != REG_OK) return s;
+    s = enqueue_match(h, true);
     if (s != REG_OK) return s;
     HIPCHK(h, hipMemsetAsync(h->i_state.p, 0, sizeof(SelectState), h->stream));
     return REG_OK;
@@ -1719,23 +1853,23 @@ reg_status reg_trim_histogram(reg_handle* h, int level, uint32_t prefix, uint32_
     return REG_OK;
 }
 
+// R5-R7 on this rank's slice for the pose given to the preceding reg_match_local
 reg_status reg_reduce_local(reg_handle* h, const float T_iter[16], float trim_limit, double sums[32]) {
     reg_status s = check_ready(h, true);
     if (s != REG_OK) return s;
     if (!h->have_match || !sums || !T_iter) return REG_BAD_ARGUMENT;
-    float Tr[16];
-    col_to_row(T_iter, Tr);
     HIPCHK(h, hipSetDevice(h->prm.device));
     SelectState st;
     std::memset(&st, 0, sizeof(st));
     st.limit = trim_limit;
     st.done = 1;
     HIPCHK(h, hipMemcpyAsync(h->i_state.p, &st, sizeof(st), hipMemcpyHostToDevice, h->stream));
-    s = enqueue_linearize(h, Tr, true, true);
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // `st` is a stack variable
+    s = enqueue_linearize(h, true, true);
     if (s != REG_OK) return s;
-    s = wait_sums(h);
+    s = wait_seq(h, h->seq);
     if (s != REG_OK) return s;
-    std::memcpy(sums, h->h_sums, kSums * 8);
+    std::memcpy(sums, h->h_mirror->sums, kSums * 8);
     return REG_OK;
 }
 
@@ -1749,7 +1883,7 @@ reg_status reg_solve_update(const reg_params* p, const double sums[32], const fl
     if (p->cost == REG_COST_P2PL) {
         sums_to_system(sums, true, H, b);
         float x[6], dT[16];
-        const int r = solve6_p2pl(H, b, x);
+        const int r = solve6_p2pl_fast(H, b, x);
         if (rank) *rank = r;
         x_to_T(x, dT);
         m4_mul(dT, Tr, Tr);
@@ -1759,7 +1893,8 @@ reg_status reg_solve_update(const reg_params* p, const double sums[32], const fl
         for (int a = 0; a < 6; ++a)
             for (int c = a; c < 6; ++c) Hd[6 * a + c] = Hd[6 * c + a] = sums[k++];
         for (int a = 0; a < 6; ++a) g[a] = -sums[21 + a];
-        const int r = solve_sym6(Hd, g, dl, 1e-12);
+        int r = 6;
+        if (!solve_ldlt6(Hd, g, dl, 1e-10)) r = solve_sym6(Hd, g, dl, 1e-12);
         if (rank) *rank = r;
         se3_exp(dl, E);
         for (int i = 0; i < 4; ++i)
@@ -1775,9 +1910,9 @@ reg_status reg_solve_update(const reg_params* p, const double sums[32], const fl
 }
 
 // ---- measurement hook -------------------------------------------------------------------------------
-// Runs `reps` iterations' worth of kernels at T_iter and reports the average device time (ms, HIP events
-// on the handle's stream) of: [0] k_match, [1] the trimmed-quantile select passes, [2] k_linearize_* +
-// k_final_reduce.  Used by bench.py for the roofline object; not part of the registration semantics.
+// Runs `reps` iterations' worth of kernels at T_iter (no pose update) and reports the average device time
+// (ms, HIP events on the handle's stream) of: [0] the match kernel, [1] the trimmed-quantile select passes,
+// [2] linearize + reduce.  Used by bench.py for the roofline object; not part of the registration semantics.
 reg_status reg_profile_kernels(reg_handle* h, const float T_iter[16], int reps, float ms[3]) {
     reg_status s = check_ready(h, true);
     if (s != REG_OK) return s;
@@ -1785,14 +1920,15 @@ reg_status reg_profile_kernels(reg_handle* h, const float T_iter[16], int reps, 
     float Tr[16];
     col_to_row(T_iter, Tr);
     HIPCHK(h, hipSetDevice(h->prm.device));
+    s = init_iter_state(h, Tr, 0);
+    if (s != REG_OK) return s;
     hipEvent_t e[4];
     for (int i = 0; i < 4; ++i) HIPCHK(h, hipEventCreate(&e[i]));
     double acc[3] = {0, 0, 0};
     const bool trim = h->prm.cost == REG_COST_P2PL && h->prm.use_trimmed;
-    for (int r = 0; r < reps; ++r) {
-        if (trim) HIPCHK(h, hipMemsetAsync(h->i_hist.p, 0, 2048 * 4, h->stream));
+    for (int r = -1; r < reps; ++r) {  // r == -1: warm-up, not counted
         HIPCHK(h, hipEventRecord(e[0], h->stream));
-        s = enqueue_match(h, Tr);
+        s = enqueue_match(h);
         if (s != REG_OK) return s;
         HIPCHK(h, hipEventRecord(e[1], h->stream));
         if (trim) {
@@ -1800,17 +1936,16 @@ reg_status reg_profile_kernels(reg_handle* h, const float T_iter[16], int reps, 
             if (s != REG_OK) return s;
         }
         HIPCHK(h, hipEventRecord(e[2], h->stream));
-        s = enqueue_linearize(h, Tr, false);
+        s = enqueue_linearize(h, false);
         if (s != REG_OK) return s;
         HIPCHK(h, hipEventRecord(e[3], h->stream));
         HIPCHK(h, hipEventSynchronize(e[3]));
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < 3 && r >= 0; ++i) {
             float t = 0;
             (void)hipEventElapsedTime(&t, e[i], e[i + 1]);
             acc[i] += t;
         }
     }
-    h->have_match = true;
     for (int i = 0; i < 3; ++i) ms[i] = (float)(acc[i] / reps);
     for (int i = 0; i < 4; ++i) (void)hipEventDestroy(e[i]);
     HIPCHK(h, hipGetLastError());

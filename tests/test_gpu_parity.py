@@ -164,3 +164,116 @@ def test_match_variants_agree_with_oracle(variant):
     T2[:3, 3] = (0.1, -0.05, 0.02)
     _check_linearize(reg, sc.tgt_xyz, sc.tgt_nrm, sc.src_xyz, sc.src_nrm, 0.5, 0.9, 1.57, T_iter=T2)
     _check_linearize(reg, sc.tgt_xyz, sc.tgt_nrm, sc.src_xyz, sc.src_nrm, 0.5, 0.9, 1.57)
+
+
+def test_gicp_linearize_and_registration_vs_float64_oracle():
+    """GICP cost (north star).  PARITY UNPINNED against the reference (its GICP arithmetic lives in the
+    un-vendored Open3D 0.15.1); pinned here against the oracle's float64 restatement:
+    ids bit-exact, H/b rtol 1e-5, final pose <= 1e-4 m / 1e-4 rad."""
+    sc = synth.make_scene(6000, 60000, seed=5)
+    p = capi.default_params()
+    p.cost = capi.COST_GICP
+    p.use_trimmed = 0
+    p.max_dist = 0.5
+    p.max_iter = 30
+    reg = capi.Registration(p)
+    reg.set_target(sc.tgt_xyz, None, sc.tgt_cov)
+    reg.set_source(sc.src_xyz, None, sc.src_cov)
+    T0 = np.eye(4, dtype=np.float32)
+    reg.prepare(T0)
+    H, b, err, cnt = reg.linearize(T0)
+    ids, d2, _ = reg.correspondences(want_w=False)
+    tree = orc.KdTree(sc.tgt_xyz)
+    oids, od2 = tree.knn(sc.src_xyz, T0, max_dist=0.5)
+    assert np.array_equal(ids, oids) and np.array_equal(d2.view(np.uint32), od2.view(np.uint32))
+    Ho, bo, eo, co = orc.gicp_normal_eq(sc.src_xyz, sc.src_cov, sc.tgt_xyz, sc.tgt_cov, T0, oids)
+    assert cnt == co
+    assert np.abs(H - Ho).max() <= 1e-5 * np.abs(Ho).max()
+    assert np.abs(b - bo).max() <= 1e-5 * np.abs(bo).max()
+    assert abs(err - eo) <= 1e-6 * eo
+    T, res = reg.register(T0)
+    To, ores = orc.icp_gicp(sc.tgt_xyz, sc.tgt_cov, sc.src_xyz, sc.src_cov, T0, max_dist=0.5, max_iter=30)
+    dt, dr = synth.pose_error(T, To)
+    assert dt <= 1e-4 and dr <= 1e-4, (dt, dr)
+    assert res.iterations == ores.iterations
+    dt, dr = synth.pose_error(T, sc.T_true)
+    assert dt < 5e-3 and dr < 1e-3, (dt, dr)
+
+
+def test_error_codes_match_reference_behaviour():
+    sc = synth.make_scene(2000, 20000, seed=3)
+    reg = capi.Registration(capi.shipped_params())
+    # empty reference: initReference returns false (ICP.cpp:850-855)
+    with pytest.raises(capi.RegError) as e:
+        reg.set_target(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
+    assert e.value.status == 1
+    # point-to-plane without normals on the reference -> InvalidField
+    with pytest.raises(capi.RegError) as e:
+        reg.set_target(sc.tgt_xyz, None)
+    assert e.value.status == 7
+    reg.set_target(sc.tgt_xyz, sc.tgt_nrm)
+    # SurfaceNormalOutlierFilter without normals on the reading -> InvalidField (DataPoints.cpp:1112)
+    with pytest.raises(capi.RegError) as e:
+        reg.set_source(sc.src_xyz, None)
+    assert e.value.status == 7
+    # empty reading (ICP.cpp:958-960)
+    with pytest.raises(capi.RegError) as e:
+        reg.set_source(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
+    assert e.value.status == 2
+    # no correspondence within maxDist -> ConvergenceError (Matches.cpp:76-80)
+    far = sc.src_xyz + np.float32(500.0)
+    reg.set_source(far, sc.src_nrm)
+    with pytest.raises(capi.RegError) as e:
+        reg.register(np.eye(4))
+    assert e.value.status == 3
+    # a bad initial transform
+    reg.set_source(sc.src_xyz, sc.src_nrm)
+    Tbad = np.eye(4, dtype=np.float32)
+    Tbad[0, 3] = np.nan
+    with pytest.raises(capi.RegError) as e:
+        reg.register(Tbad)
+    assert e.value.status == 4
+    # and the handle is still usable afterwards
+    T, res = reg.register(np.eye(4))
+    assert synth.pose_error(T, sc.T_true)[0] < 1e-2
+
+
+def test_stride4_features_layout_and_degenerate_plane():
+    """DataPoints::features layout ({x,y,z,1}, stride 4) and the icpSingular case of the reference's own
+    tests (utest.cpp:163-199): a 10x10 planar grid shifted by 1 in z must give a pure z translation."""
+    nX = 10
+    d = 0.1
+    g = np.arange(nX) * d - nX * d / 2
+    xx, yy = np.meshgrid(g, g, indexing="ij")
+    pts0 = np.stack([xx.ravel(), yy.ravel(), np.zeros(nX * nX), np.ones(nX * nX)], axis=1).astype(np.float32)
+    pts1 = pts0.copy()
+    pts1[:, 2] = 1.0
+    nrm = np.tile(np.array([[0, 0, 1]], np.float32), (nX * nX, 1))
+    p = capi.default_params()
+    p.trim_ratio = 1.0           # default-identity.yaml: TrimmedDist ratio 1.0, Counter 40, Differential 0.001/0.01/4
+    p.min_diff_trans = 0.01
+    p.smooth_len = 4
+    reg = capi.Registration(p)
+    reg.set_target(pts1, nrm)    # reference = shifted cloud, stride 4
+    reg.set_source(pts0)
+    T, res = reg.register(np.eye(4))
+    expected = np.eye(4, dtype=np.float32)
+    expected[2, 3] = 1.0
+    assert np.allclose(T, expected, atol=1e-5), T
+    assert res.rank_last == 3
+    To, _ = orc.icp_p2pl(pts1[:, :3], nrm, pts0[:, :3], trim_ratio=1.0, max_iter=40, min_diff_trans=0.01, smooth_len=4)
+    assert np.allclose(To, expected, atol=1e-5)
+
+
+def test_identity_registration_of_a_cloud_with_itself():
+    """icpIdentity of the reference's tests (utest.cpp:201-221), epsilon 1e-4."""
+    ref, _ = _car()
+    p = capi.default_params()
+    p.trim_ratio = 1.0
+    p.min_diff_trans = 0.01
+    p.smooth_len = 4
+    reg = capi.Registration(p)
+    reg.set_target(ref[:, :3], ref[:, 3:6])
+    reg.set_source(ref[:, :3])
+    T, res = reg.register(np.eye(4))
+    assert np.allclose(T, np.eye(4), atol=1e-4), T
