@@ -277,3 +277,15 @@ def test_identity_registration_of_a_cloud_with_itself():
     reg.set_source(ref[:, :3])
     T, res = reg.register(np.eye(4))
     assert np.allclose(T, np.eye(4), atol=1e-4), T
+
+
+def test_cpp_mirror_demo_runs():
+    """The header-only C++ mirror (include/o3dslam_icp.hpp) drives the same C ABI; built by __graft_entry__.build()."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(GOLD), "..", "examples", "icp_demo")
+    exe = os.path.abspath(exe)
+    if not os.path.exists(exe):
+        pytest.skip("examples/icp_demo not built")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "OK" in out.stdout
