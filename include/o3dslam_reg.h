@@ -106,6 +106,8 @@ typedef struct {
     float   target_build_ms;    /* last reg_set_target: upload + voxel-bin build */
     float   loop_ms;            /* iteration loop of the last reg_register (device time, HIP events) */
     float   T_iter_last[16];    /* final T_iter (column-major): P2PL in the centred frames, GICP == T_out */
+    int32_t n_band_stalls;      /* fused path: iterations whose trimmed-band prediction failed and were re-run on the generic path */
+    int32_t reserved;
 } reg_result;
 
 /* ICPChainBase::setDefault (ICP.cpp:100-113): knn 1, eps 0, maxDist inf, Trimmed 0.85,

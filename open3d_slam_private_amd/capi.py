@@ -40,7 +40,7 @@ class RegResult(C.Structure):
                 ("rank_last", C.c_int32), ("n_inliers", C.c_int64), ("n_matched", C.c_int64), ("error", C.c_double),
                 ("fitness", C.c_double), ("inlier_rmse", C.c_double), ("H_last", C.c_float * 36),
                 ("b_last", C.c_float * 6), ("target_build_ms", C.c_float), ("loop_ms", C.c_float),
-                ("T_iter_last", C.c_float * 16)]
+                ("T_iter_last", C.c_float * 16), ("n_band_stalls", C.c_int32), ("reserved", C.c_int32)]
 
 
 class TargetInfo(C.Structure):

@@ -36,15 +36,36 @@ struct IterState {
     int update;           // 0: reduce only (reg_linearize / distributed halves), 1: solve + update + check
     float gicp_rot_eps, gicp_trans_eps;
     double sums[kSums];
+    // fused path (k_iter_fused): predicted band [band_lo, band_hi) around the trimmed-quantile limit
+    float band_lo, band_hi;   // +inf / +inf: no trimming (every finite match is inside)
+    float trim_ratio;
+    int use_trim;             // 1: TrimmedDistOutlierFilter active
+    int stall;                // 1: the band prediction failed; enqueued fused kernels return until the host repairs
+    float limit_last;         // trimmed limit of the last completed iteration (+inf: none)
+    float limit_prev;         // ... and of the one before
+    unsigned int band_count;  // records appended to the band buffer in this iteration
+    unsigned int band_cap;
 };
 
 // What the update kernel mirrors into mapped host memory (the host polls `seq`).
 struct HostMirror {
     double sums[kSums];
     float T[16];
-    int iterations, done, status, rank_last, converged, max_iter_reached, pad0, pad1;
+    int iterations, done, status, rank_last, converged, max_iter_reached, stall, band_count;
+    float limit_last, limit_prev, band_lo, band_hi;
+    int pad_nband, pad2;
+    unsigned long long stamps[8];   // s_memtime stamps of the update kernel (diagnostics only; nothing reads them)
     unsigned long long seq;
 };
+
+// XCD-aware workgroup order: the dispatcher deals workgroups round-robin over the 8 XCDs (blockIdx % 8
+// shares an XCD).  With a Morton-ordered reading, giving each XCD ONE contiguous eighth of the reading means
+// its private 4 MB L2 only has to hold that region's slice of the reference cloud and tables.
+// Launch with gridDim.x = 8 * ceil(n_blocks / 8); returns the logical block (>= n_blocks: nothing to do).
+__device__ __forceinline__ int xcd_block(int n_blocks) {
+    const int chunk = (n_blocks + 7) >> 3;
+    return (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+}
 
 __device__ __forceinline__ Xf load_xf(const IterState* it) {
     Xf x;
@@ -192,6 +213,34 @@ __global__ void k_fill_tables(const uint64_t* __restrict__ keys, const uint32_t*
     if (old == 0) atomicAdd(occupied, 1u);
 }
 
+// Halo bins: every reference point is listed in each bin whose box, grown by rho_h, contains it.
+struct HaloCfg {
+    float ox, oy, oz, inv_c, r_ins;  // r_ins = rho_h + safety margin
+    int dimx, dimy, dimz;
+};
+__device__ __forceinline__ void halo_range(float v, float o, float inv_c, float r, int dim, int& lo, int& hi) {
+    lo = (int)fminf(fmaxf(bin_coord_f(v - r, o, inv_c), 0.f), (float)(dim - 1));
+    hi = (int)fminf(fmaxf(bin_coord_f(v + r, o, inv_c), 0.f), (float)(dim - 1));
+}
+// pass 0: count, pass 1: fill (cursor = running insert position per bin)
+__global__ void k_halo_insert(const float4* __restrict__ pts_sorted, int64_t n, HaloCfg c, int pass,
+                              uint32_t* __restrict__ counts_or_cursor, float4* __restrict__ halo_pts) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pts_sorted[i];
+    int x0, x1, y0, y1, z0, z1;
+    halo_range(p.x, c.ox, c.inv_c, c.r_ins, c.dimx, x0, x1);
+    halo_range(p.y, c.oy, c.inv_c, c.r_ins, c.dimy, y0, y1);
+    halo_range(p.z, c.oz, c.inv_c, c.r_ins, c.dimz, z0, z1);
+    for (int z = z0; z <= z1; ++z)
+        for (int y = y0; y <= y1; ++y)
+            for (int x = x0; x <= x1; ++x) {
+                const size_t B = ((size_t)z * c.dimy + y) * c.dimx + x;
+                const uint32_t slot = atomicAdd(&counts_or_cursor[B], 1u);
+                if (pass == 1) halo_pts[slot] = make_float4(p.x, p.y, p.z, __uint_as_float((uint32_t)i));
+            }
+}
+
 // =================================================================================================
 // kernels: reading preparation (R2)
 // =================================================================================================
@@ -297,12 +346,13 @@ k_match(const float4* __restrict__ src, int64_t n, const IterState* __restrict__
     }
 }
 
-// Cooperative variant: 8 lanes per reading point (32 points per 256-thread workgroup).
+// Cooperative variant: G (8 or 4) lanes per reading point (256/G points per 256-thread workgroup).
 // `hint` (one byte per point, may be null) carries the terminating level of the previous iteration.
+template <int G>
 __global__ void __launch_bounds__(256)
 k_match_g8(const float4* __restrict__ src, int64_t n, const IterState* __restrict__ it, Grid g, int* __restrict__ pos,
            float* __restrict__ d2, uint32_t* __restrict__ hist0 /* 2048 or null */,
-           uint32_t* __restrict__ hist2_to_zero, uint8_t* __restrict__ hint, int shift0) {
+           uint32_t* __restrict__ hist2_to_zero, uint8_t* __restrict__ hint, int shift0, int debug, int n_blocks) {
     __shared__ uint32_t sh[2048];
     if (it->done) return;
     const Xf T = load_xf(it);
@@ -312,19 +362,30 @@ k_match_g8(const float4* __restrict__ src, int64_t n, const IterState* __restric
         for (int k = threadIdx.x; k < 2048; k += blockDim.x) sh[k] = 0;
         __syncthreads();
     }
-    const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    const int64_t q = tid >> 3;
-    const int sub = (int)(tid & (kGroup - 1));
+    const int lb = xcd_block(n_blocks);
+    const int64_t tid = lb * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t q = lb < n_blocks ? (tid / G) : n;
+    const int sub = (int)(tid & (G - 1));
     if (q < n) {
         const float4 s = src[q];
         const float3 p = xf_point(T, s.x, s.y, s.z);
-        const int first = hint ? max((int)hint[q] - 1, 0) : 0;
+        if (debug & 4) {  // timing experiment: fixed cost of the launch + reading load only
+            if (sub == 0) {
+                pos[q] = -1;
+                d2[q] = p.x;
+            }
+            return;
+        }
+        // hint h: 0/1 = the last search ended at the halo level / regular level 0 -> try the halo first;
+        // h >= 2 = it ended at regular level h-1 -> skip the halo and start one regular level below.
+        const int hv = hint ? (int)hint[q] : 0;
+        const int first = hv >= 2 ? hv - 2 : -1;
         int lvl;
-        const Best b = nearest_group(g, p, sub, first, &lvl);
+        const Best b = nearest_group<G>(g, p, sub, first, &lvl);
         if (sub == 0) {
             pos[q] = b.pos;
             d2[q] = b.pos >= 0 ? b.d2 : INFINITY;
-            if (hint) hint[q] = (uint8_t)lvl;
+            if (hint) hint[q] = (uint8_t)(lvl + 1);
             if (hist0 && b.pos >= 0) atomicAdd(&sh[__float_as_uint(b.d2) >> shift0], 1u);
         }
     }
@@ -501,6 +562,7 @@ k_hist_prefix(const float* __restrict__ d2, int64_t n, int level, uint32_t prefi
 
 struct FilterCfg {
     int use_trim, use_normal, use_maxdist;
+    int debug;   // ablation switches for kernel timing experiments (0 in production)
     float cos_max_angle;
     float outlier_max_d2;
 };
@@ -595,7 +657,7 @@ k_linearize_p2pl(const float4* __restrict__ src, const float4* __restrict__ src_
             if (f.use_trim && !(dd <= limit)) w = 0.f;
             const float4 s = src[i];
             const float3 p = xf_point(T, s.x, s.y, s.z);
-            const float4 nn = tgt_nrm[ps];
+            const float4 nn = (f.debug & 1) ? make_float4(0.f, 0.f, 1.f, 0.f) : tgt_nrm[ps];
             if (f.use_normal) {
                 const float4 sn = src_nrm[i];
                 const float3 nr = normalize3(xf_rot(T, sn.x, sn.y, sn.z));
@@ -608,7 +670,7 @@ k_linearize_p2pl(const float4* __restrict__ src, const float4* __restrict__ src_
                 if (val < f.cos_max_angle) w = 0.f;
             }
             if (w != 0.f) {
-                const float4 q = tgt[ps];
+                const float4 q = (f.debug & 1) ? make_float4(s.x, s.y, s.z, 0.f) : tgt[ps];
                 float F[6];
                 float a = p.y * nn.z, b = p.z * nn.y;
                 F[0] = a - b;
@@ -646,6 +708,12 @@ k_linearize_p2pl(const float4* __restrict__ src, const float4* __restrict__ src_
             }
         }
         if (w_out) w_out[i] = w;
+    }
+    if (f.debug & 2) {
+        double t = 0;
+        for (int k = 0; k < kSums; ++k) t += v[k];
+        if (t == 1.2345) partials[0] = t;
+        return;
     }
     block_reduce_store(v, partials);
 }
@@ -760,29 +828,337 @@ k_linearize_gicp(const float4* __restrict__ src, const float4* __restrict__ src_
     block_reduce_store(v, partials);
 }
 
-// Last kernel of an iteration: fixed-order sum of the workgroup partials, then (it->update) R8 + R9 on
-// the device -- 6x6 solve in fp64, x -> 4x4, T_iter <- dT * T_iter, transformation checkers -- and a
-// mirror of the outcome into mapped host memory followed by a sequence word the host polls.
+// =================================================================================================
+// Fused iteration kernel (north star: KNN fused into the Jacobian / normal-equation accumulation)
+// =================================================================================================
+// One launch does R3 + R4 + R5 + R6 + R7 for a group's reading point: search, weights, F, r, the 27 products.
+// The trimmed-quantile limit of THIS iteration is not known yet, so points are classified against a band
+// [lo, hi) predicted from the previous iteration: d2 < lo -> certainly kept, d2 >= hi -> certainly trimmed,
+// lo <= d2 < hi -> a 32-float record {d2, products, flags, point} is appended to a small buffer.  The update
+// kernel verifies the prediction with exact counts (n_below <= k < n_below + n_band), picks the exact k-th
+// smallest d2 inside the band, adds the surviving records, and only then solves.  A failed prediction stalls
+// the queue; the host re-runs that iteration on the generic (select-based) path.  Results are identical to
+// the generic path by construction: same products, same fp64 accumulation, exact quantile.
+constexpr int kBandCap = 16384;
+constexpr int kAccRows = 64;   // replicas of the 32-double accumulator (spreads the fp64 atomics)
+constexpr int kRec = 32;   // floats per band record
+
+// products for one reading point: vals[0..20] = F_a F_c (upper triangle), [21..26] = F_a r, [27] = r^2
+__device__ __forceinline__ void p2pl_products(float3 p, float4 q, float4 nn, float w, float* vals) {
+    float F[6];
+    float a = p.y * nn.z, b = p.z * nn.y;
+    F[0] = a - b;
+    a = p.z * nn.x; b = p.x * nn.z;
+    F[1] = a - b;
+    a = p.x * nn.y; b = p.y * nn.x;
+    F[2] = a - b;
+    F[3] = nn.x; F[4] = nn.y; F[5] = nn.z;
+    const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
+    float r = dx * nn.x;
+    float t2 = dy * nn.y;
+    r = r + t2;
+    t2 = dz * nn.z;
+    r = r + t2;
+    int k = 0;
+#pragma unroll
+    for (int a6 = 0; a6 < 6; ++a6) {
+        const float wf = w * F[a6];
+#pragma unroll
+        for (int c6 = a6; c6 < 6; ++c6) vals[k++] = wf * F[c6];
+    }
+#pragma unroll
+    for (int a6 = 0; a6 < 6; ++a6) {
+        const float wf = w * F[a6];
+        vals[21 + a6] = wf * r;
+    }
+    const float rr = r * r;
+    vals[27] = w * rr;
+}
+
+template <int G>
+__global__ void __launch_bounds__(256)
+k_iter_fused(const float4* __restrict__ src, const float4* __restrict__ src_nrm, int64_t n, IterState* __restrict__ it,
+             Grid g, const float4* __restrict__ tgt_nrm, FilterCfg f, int* __restrict__ pos_out,
+             float* __restrict__ d2_out, float* __restrict__ w_out, uint8_t* __restrict__ hint,
+             float* __restrict__ band, double* __restrict__ partials, int n_blocks) {
+    constexpr int CP = kSums / G;   // components owned by each lane of a group
+    __shared__ double sh[4][kSums];
+    if (it->done || it->stall) return;
+    const Xf T = load_xf(it);
+    const float band_lo = it->band_lo, band_hi = it->band_hi;
+    const int lb = xcd_block(n_blocks);
+    const int64_t tid = lb * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t q = lb < n_blocks ? (tid / G) : n;
+    const int sub = (int)(tid & (G - 1));
+    double mine[CP];
+#pragma unroll
+    for (int j = 0; j < CP; ++j) mine[j] = 0.0;
+    if (q < n) {
+        const float4 s = src[q];
+        const float3 p = xf_point(T, s.x, s.y, s.z);
+        const int hv = hint ? (int)hint[q] : 0;
+        int lvl;
+        const Best b = nearest_group<G>(g, p, sub, hv >= 2 ? hv - 2 : -1, &lvl);
+        float vals[kSums];
+#pragma unroll
+        for (int k = 0; k < kSums; ++k) vals[k] = 0.f;
+        float w = 0.f;
+        int cls = 2;  // 0: certainly kept, 1: band, 2: dropped / unmatched
+        if (b.pos >= 0) {
+            const float dd = b.d2;
+            vals[29] = 1.f;
+            w = 1.f;
+            if (f.use_maxdist && !(dd <= f.outlier_max_d2)) w = 0.f;
+            const float4 nn = tgt_nrm[b.pos];
+            if (f.use_normal) {
+                const float4 sn = src_nrm[q];
+                const float3 nr = normalize3(xf_rot(T, sn.x, sn.y, sn.z));
+                const float3 nt = normalize3(make_float3(nn.x, nn.y, nn.z));
+                float a = nr.x * nt.x;
+                float bb = nr.y * nt.y;
+                float val = a + bb;
+                a = nr.z * nt.z;
+                val = val + a;
+                if (val < f.cos_max_angle) w = 0.f;
+            }
+            cls = dd < band_lo ? 0 : (dd < band_hi ? 1 : 2);
+            if (cls == 0) vals[31] = 1.f;   // counts towards n_below (rank bookkeeping is independent of w)
+            if (w != 0.f && cls != 2) {
+                const float4 tq = g.pts[b.pos];
+                p2pl_products(p, tq, nn, w, vals);
+                vals[28] = 1.f;
+                vals[30] = dd;
+            }
+            if (cls == 1 && sub == 0) {
+                // band record: decided by the update kernel
+                const unsigned slot = atomicAdd(&it->band_count, 1u);
+                if (slot < (unsigned)kBandCap) {
+                    float* rec = band + (size_t)slot * kRec;
+#pragma unroll
+                    for (int k = 0; k < 31; ++k) rec[k] = vals[k];
+                    rec[29] = dd;                            // [29] = d2 (the "matched" count is added from cls below)
+                    rec[31] = __int_as_float((int)q);
+                }
+            }
+        }
+        if (sub == 0) {
+            pos_out[q] = b.pos;
+            d2_out[q] = b.pos >= 0 ? b.d2 : INFINITY;
+            if (hint) hint[q] = (uint8_t)(lvl + 1);
+            if (w_out) w_out[q] = (cls == 2) ? 0.f : w;   // band points: provisional, patched by the update kernel
+        }
+        // certainly-kept contributions: lane `sub` owns components sub*CP .. sub*CP+CP-1
+        if (cls == 1) {
+#pragma unroll
+            for (int k = 0; k < 29; ++k) vals[k] = 0.f;   // deferred
+            vals[30] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < CP; ++j) {
+            float v = 0.f;
+#pragma unroll
+            for (int sIdx = 0; sIdx < G; ++sIdx)
+                if (sub == sIdx) v = vals[sIdx * CP + j];
+            mine[j] = (double)v;
+        }
+    }
+    // sum over the groups of the wave (same `sub` lanes), then over the 4 waves
+#pragma unroll
+    for (int m = G; m < 64; m <<= 1)
+#pragma unroll
+        for (int j = 0; j < CP; ++j) mine[j] += __shfl_xor(mine[j], m);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < G)
+#pragma unroll
+        for (int j = 0; j < CP; ++j) sh[wave][lane * CP + j] = mine[j];
+    __syncthreads();
+    if (threadIdx.x < kSums && lb < n_blocks) {
+        const double t = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+        // one 256-byte fp64 atomic wave-instruction per workgroup into one of kAccRows replicas (memory-side
+        // atomics; the update kernel sums the replicas in a fixed order and clears them)
+        unsafeAtomicAdd(&partials[(size_t)(lb & (kAccRows - 1)) * kSums + threadIdx.x], t);
+    }
+}
+
+// Block-wide (1024 threads): bin with cum[b] <= rank < cum[b+1] over h[0..nb), nb <= 2048 (2 bins per thread).
+__device__ __forceinline__ void block_pick1024(const uint32_t* h, int nb, uint32_t rank, uint32_t* wave_tot /*[16]*/,
+                                               uint32_t* out /*[0]=bin, [1]=rank inside the bin*/) {
+    const int t = threadIdx.x;
+    const uint32_t a = (2 * t < nb) ? h[2 * t] : 0u;
+    const uint32_t b = (2 * t + 1 < nb) ? h[2 * t + 1] : 0u;
+    const uint32_t sum = a + b;
+    uint32_t incl = sum;
+    const int lane = t & 63, wave = t >> 6;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    if (t == 0) {
+        out[0] = 0;
+        out[1] = 0;
+    }
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; ++w) base += wave_tot[w];
+    const uint32_t excl = base + incl - sum;
+    if (a && rank >= excl && rank < excl + a) {
+        out[0] = 2 * t;
+        out[1] = rank - excl;
+    }
+    if (b && rank >= excl + a && rank < excl + a + b) {
+        out[0] = 2 * t + 1;
+        out[1] = rank - excl - a;
+    }
+    __syncthreads();
+}
+
+// Last kernel of an iteration: fixed-order sum of the workgroup partials; (fused path) verification of the
+// predicted trimmed band + exact quantile inside it + the surviving band records; then (it->update) R8 + R9 on
+// the device -- 6x6 solve in fp64, x -> 4x4, T_iter <- dT * T_iter, transformation checkers -- and a mirror of
+// the outcome into mapped host memory followed by a sequence word the host polls.
 __global__ void __launch_bounds__(1024)
 k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it, HostMirror* host,
-                unsigned long long seq) {
+                unsigned long long seq, int fused, const float* __restrict__ band, float* __restrict__ w_out,
+                const SelectState* __restrict__ sel) {
     __shared__ double sh[32][kSums];
     __shared__ double tot[kSums];
+    __shared__ uint32_t hist[2048];
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t pick[2];
+    __shared__ float s_limit;
+    __shared__ uint32_t bd2[kBandCap];
     if (it->done) return;
+    if (fused && it->stall) return;
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime();
     const int comp = threadIdx.x & (kSums - 1), part = threadIdx.x / kSums;  // 32 parts x 32 comps
     double t = 0;
-    for (int b = part; b < n_blocks; b += 32) t += partials[(size_t)b * kSums + comp];
+    if (fused) {
+        for (int b = part; b < kAccRows; b += 32) {
+            t += partials[(size_t)b * kSums + comp];
+            const_cast<double*>(partials)[(size_t)b * kSums + comp] = 0.0;   // ready for the next iteration
+        }
+    } else {
+        for (int b = part; b < n_blocks; b += 32) t += partials[(size_t)b * kSums + comp];
+    }
     sh[part][comp] = t;
+    if (threadIdx.x == 0) {
+        s_limit = INFINITY;
+    }
     __syncthreads();
     if (threadIdx.x < kSums) {
         double s = 0;
         for (int p = 0; p < 32; ++p) s += sh[p][threadIdx.x];
         tot[threadIdx.x] = s;
-        it->sums[threadIdx.x] = s;
-        host->sums[threadIdx.x] = s;
     }
     __syncthreads();
+    const bool trim = it->use_trim && it->trim_ratio != 1.0f;
+    const unsigned long long stA = __builtin_amdgcn_s_memtime();
+    unsigned long long stB = stA, stC = stA;
+    if (fused && trim) {
+        // ---- verify the predicted band with exact counts, then select the exact quantile inside it
+        const uint32_t n_finite = (uint32_t)llround(tot[29]), n_below = (uint32_t)llround(tot[31]);
+        const uint32_t n_band = it->band_count;
+        const uint32_t k = trim_rank(n_finite, it->trim_ratio);
+        const bool ok = n_finite == 0 || (n_band <= (uint32_t)kBandCap && n_below <= k && k < n_below + n_band);
+        if (!ok) {
+            if (threadIdx.x == 0) {
+                it->stall = 1;
+                it->band_count = 0;
+                host->stall = 1;
+                host->band_count = (int)n_band;
+                host->iterations = it->iterations;
+                host->done = 0;
+                __threadfence_system();
+                __hip_atomic_store(&host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            return;
+        }
+        if (n_finite != 0) {
+            // stage the band's d2 bit patterns in LDS once; the three radix levels then run out of LDS
+            for (uint32_t i = threadIdx.x; i < n_band; i += 1024) bd2[i] = __float_as_uint(band[(size_t)i * kRec + 29]);
+            uint32_t rank = k - n_below, prefix = 0;
+            for (int level = 0; level < 3; ++level) {
+                for (int i = threadIdx.x; i < 2048; i += 1024) hist[i] = 0;
+                __syncthreads();
+                const uint32_t mask = level == 0 ? 0u : (level == 1 ? 0xffe00000u : 0xfffffc00u);
+                for (uint32_t i = threadIdx.x; i < n_band; i += 1024) {
+                    const uint32_t u = bd2[i];
+                    if ((u & mask) == prefix)
+                        atomicAdd(&hist[level == 0 ? (u >> 21) : (level == 1 ? ((u >> 10) & 2047u) : (u & 1023u))], 1u);
+                }
+                __syncthreads();
+                block_pick1024(hist, level == 2 ? 1024 : 2048, rank, wave_tot, pick);
+                prefix |= pick[0] << (level == 0 ? 21 : (level == 1 ? 10 : 0));
+                rank = pick[1];
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) s_limit = __uint_as_float(prefix);
+            __syncthreads();
+            stB = __builtin_amdgcn_s_memtime();
+            const float limit = s_limit;
+            // ---- add the band records that survive the trim (component-wise, 32 parts)
+            // (8 records in flight per thread: a dependent load per record would cost a memory latency each)
+            double acc = 0;
+            if (comp != 29 && comp != 31)
+                for (uint32_t i0 = part; i0 < n_band; i0 += 32 * 16) {
+                    float vv[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const uint32_t i = min(i0 + 32u * u, n_band - 1);
+                        vv[u] = band[(size_t)i * kRec + comp];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const uint32_t i = i0 + 32u * u;
+                        if (i < n_band && __uint_as_float(bd2[i]) <= limit) acc += (double)vv[u];
+                    }
+                }
+            sh[part][comp] = acc;
+            if (w_out)
+                for (uint32_t i = threadIdx.x; i < n_band; i += 1024) {
+                    const float* rec = band + (size_t)i * kRec;
+                    if (!(__uint_as_float(bd2[i]) <= limit)) w_out[__float_as_int(rec[31])] = 0.f;
+                }
+            __syncthreads();
+            if (threadIdx.x < kSums) {
+                double s2 = 0;
+                for (int p = 0; p < 32; ++p) s2 += sh[p][threadIdx.x];
+                tot[threadIdx.x] += s2;
+            }
+            __syncthreads();
+            stC = __builtin_amdgcn_s_memtime();
+        }
+    } else if (!fused && trim && sel) {
+        if (threadIdx.x == 0) s_limit = sel->limit;
+        __syncthreads();
+    }
+    if (threadIdx.x < kSums) {
+        it->sums[threadIdx.x] = tot[threadIdx.x];
+        host->sums[threadIdx.x] = tot[threadIdx.x];
+    }
     if (threadIdx.x != 0) return;
+    const unsigned long long st1 = __builtin_amdgcn_s_memtime();
+    unsigned long long st2 = st1, st3 = st1;
+    // band for the next iteration from the limits seen so far
+    {
+        const float limit = s_limit;
+        it->limit_prev = it->limit_last;
+        it->limit_last = limit;
+        if (!trim || !(limit < INFINITY)) {
+            it->band_lo = INFINITY;   // no trimming / nothing to predict from: every finite match is "certainly kept"
+            it->band_hi = INFINITY;
+        } else {
+            const float prev = it->limit_prev;
+            float m = 0.3f;
+            if (prev < INFINITY && prev > 0.f) m = fminf(fmaxf(2.0f * fabsf(limit - prev) / limit + 0.01f, 0.01f), 0.6f);
+            it->band_lo = limit * (1.0f - m);
+            it->band_hi = limit * (1.0f + m);
+        }
+        host->pad_nband = (int)it->band_count;
+        it->band_count = 0;
+        it->stall = 0;
+    }
     if (it->update) {
         if (tot[28] == 0.0) {
             it->status = REG_NO_CORRESPONDENCES;
@@ -798,6 +1174,7 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
                 }
             for (int a = 0; a < 6; ++a) b6[a] = -(float)tot[21 + a];
             it->rank_last = solve6_p2pl_fast(H, b6, x);
+            st2 = __builtin_amdgcn_s_memtime();
             x_to_T(x, dT);
             m4_mul(dT, it->T, Tn);  // T_iter = real * T_iter (ICP.cpp:1213-1215)
             for (int i = 0; i < 16; ++i) it->T[i] = Tn[i];
@@ -808,6 +1185,7 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
             else
                 iterate = it->chk.check(Tn);
             if (!iterate) it->done = 1;
+            st3 = __builtin_amdgcn_s_memtime();
         } else {
             double Hd[36], g[6], dl[6], E[16], Tn[16];
             int k = 0;
@@ -851,6 +1229,20 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
     host->rank_last = it->rank_last;
     host->converged = it->chk.converged ? 1 : 0;
     host->max_iter_reached = it->chk.max_iter_reached ? 1 : 0;
+    host->stall = 0;
+    host->band_count = 0;
+    host->limit_last = it->limit_last;
+    host->limit_prev = it->limit_prev;
+    host->band_lo = it->band_lo;
+    host->band_hi = it->band_hi;
+    host->stamps[0] = st1 - st0;
+    host->stamps[1] = st2 - st1;
+    host->stamps[2] = st3 - st2;
+    host->stamps[3] = __builtin_amdgcn_s_memtime() - st3;
+    host->stamps[4] = stA - st0;
+    host->stamps[5] = stB - stA;
+    host->stamps[6] = stC - stB;
+    host->stamps[7] = it->band_count;
     __threadfence_system();
     __hip_atomic_store(&host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -929,8 +1321,10 @@ struct reg_handle {
     IterState* h_iter = nullptr;      // pinned staging copy of the iteration state
     DevBuf i_iter;                    // IterState on the device
     unsigned long long seq = 0;
+    DevBuf t_halo_start, t_halo_cursor, t_halo_pts, i_band, i_acc;
     DevBuf i_hint, s_keys, s_keys2, s_perm, s_perm2, s_tmp, i_tmpf;
     const uint32_t* perm = nullptr;   // slot -> input index (null: identity)
+    int last_stalls = 0;
     int shift0 = 21;                  // low bit of the level-0 radix digit (19 when max_dist^2 < 2: bits 31,30 are 0)
     int n_blocks = 0;
     bool have_match = false;
@@ -1039,7 +1433,7 @@ void reg_destroy(reg_handle* h) {
                       &h->t_vals2, &h->t_pts, &h->t_nrm, &h->t_cov, &h->t_flags, &h->t_scan, &h->t_hash, &h->t_cells,
                       &h->t_tmp, &h->t_misc, &h->s_raw, &h->s_nrm_raw, &h->s_cov_raw, &h->s_xyz, &h->s_nrm, &h->s_cov,
                       &h->s_misc, &h->i_pos, &h->i_d2, &h->i_w, &h->i_hist, &h->i_state, &h->i_partials, &h->i_sums,
-                      &h->i_ids, &h->i_iter, &h->i_hint, &h->s_keys, &h->s_keys2, &h->s_perm, &h->s_perm2, &h->s_tmp, &h->i_tmpf};
+                      &h->i_ids, &h->i_iter, &h->t_halo_start, &h->t_halo_cursor, &h->t_halo_pts, &h->i_band, &h->i_acc, &h->i_hint, &h->s_keys, &h->s_keys2, &h->s_perm, &h->s_perm2, &h->s_tmp, &h->i_tmpf};
     for (DevBuf* b : bufs) b->release();
     if (h->h_mirror) (void)hipHostFree(h->h_mirror);
     if (h->h_iter) (void)hipHostFree(h->h_iter);
@@ -1201,6 +1595,73 @@ static void set_levels(reg_handle* h, float c, float max_abs) {
     g.n_levels = n;
 }
 
+// Level-0 accelerator: dense halo bins of edge c_h = 1.5 c with rho_h = c_h / 4 (each point is listed in
+// 1-2 bins per axis: ~3.4 copies).  Skipped when the dense grid would be too large or on request.
+static reg_status build_halo(reg_handle* h, float c, const float bmin[3], const float bmax[3], float max_abs) {
+    Grid& g = h->grid;
+    g.use_halo = 0;
+    g.level_after_halo = 0;
+    if (h->prm.reserved[1] == 1) return REG_OK;  // reserved[1] == 1: halo level disabled (A/B experiments)
+    const float ch = 1.5f * c;
+    const float abs_margin = 4e-7f * (1.0f + max_abs);
+    const float rho_h = 0.25f * ch * (1.0f - 4e-3f) - 2.f * abs_margin;
+    if (!(rho_h > 0.f)) return REG_OK;
+    const float r_ins = rho_h + 1e-3f * rho_h + abs_margin;
+    const float inv = 1.0f / ch;
+    double dims[3];
+    for (int k = 0; k < 3; ++k) dims[k] = std::floor((double)(bmax[k] - bmin[k]) * inv) + 1.0;
+    const double nb = dims[0] * dims[1] * dims[2];
+    if (nb > 48e6) return REG_OK;
+    const size_t nbins = (size_t)nb;
+    HaloCfg hc;
+    hc.ox = bmin[0];
+    hc.oy = bmin[1];
+    hc.oz = bmin[2];
+    hc.inv_c = inv;
+    hc.r_ins = r_ins;
+    hc.dimx = (int)dims[0];
+    hc.dimy = (int)dims[1];
+    hc.dimz = (int)dims[2];
+    HIPCHK(h, h->t_halo_start.reserve((nbins + 1) * 4));
+    HIPCHK(h, h->t_halo_cursor.reserve((nbins + 1) * 4));
+    HIPCHK(h, hipMemsetAsync(h->t_halo_start.p, 0, (nbins + 1) * 4, h->stream));
+    k_halo_insert<<<grid_for(h->m), 256, 0, h->stream>>>(h->t_pts.as<float4>(), h->m, hc, 0,
+                                                         h->t_halo_start.as<uint32_t>(), nullptr);
+    size_t ex_bytes = 0;
+    HIPCHK(h, rocprim::exclusive_scan(nullptr, ex_bytes, h->t_halo_start.as<uint32_t>(), h->t_halo_start.as<uint32_t>(),
+                                      0u, nbins + 1, rocprim::plus<uint32_t>(), h->stream));
+    HIPCHK(h, h->t_tmp.reserve(ex_bytes));
+    HIPCHK(h, rocprim::exclusive_scan(h->t_tmp.p, ex_bytes, h->t_halo_start.as<uint32_t>(),
+                                      h->t_halo_start.as<uint32_t>(), 0u, nbins + 1, rocprim::plus<uint32_t>(),
+                                      h->stream));
+    uint32_t total = 0;
+    HIPCHK(h, hipMemcpyAsync(&total, h->t_halo_start.as<uint32_t>() + nbins, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->t_halo_cursor.p, h->t_halo_start.p, nbins * 4, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, h->t_halo_pts.reserve((size_t)std::max<uint32_t>(total, 1) * 16));
+    k_halo_insert<<<grid_for(h->m), 256, 0, h->stream>>>(h->t_pts.as<float4>(), h->m, hc, 1,
+                                                         h->t_halo_cursor.as<uint32_t>(), h->t_halo_pts.as<float4>());
+    g.use_halo = 1;
+    g.hox = hc.ox;
+    g.hoy = hc.oy;
+    g.hoz = hc.oz;
+    g.hinv_c = inv;
+    g.hdimx = hc.dimx;
+    g.hdimy = hc.dimy;
+    g.hdimz = hc.dimz;
+    g.halo_start = h->t_halo_start.as<uint32_t>();
+    g.halo_pts = h->t_halo_pts.as<float4>();
+    g.rho_h = rho_h;
+    g.level_after_halo = g.n_levels - 1;
+    for (int l = 0; l < g.n_levels; ++l)
+        if (g.rho[l] > rho_h) {
+            g.level_after_halo = l;
+            break;
+        }
+    h->info.table_bytes += (int64_t)((nbins + 1) * 4 + (size_t)total * 16);
+    return REG_OK;
+}
+
 extern "C" {
 
 reg_status reg_set_target(reg_handle* h, const float* xyz, int64_t xyz_stride, const float* nrm, int64_t nrm_stride,
@@ -1312,6 +1773,10 @@ reg_status reg_set_target(reg_handle* h, const float* xyz, int64_t xyz_stride, c
                                                          d_cov ? h->t_cov.as<float4>() : nullptr);
     h->grid.pts = h->t_pts.as<float4>();
     set_levels(h, cs, max_abs);
+    {
+        reg_status hs = build_halo(h, cs, bmin, bmax, max_abs);
+        if (hs != REG_OK) return hs;
+    }
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
@@ -1375,7 +1840,9 @@ reg_status reg_set_source(reg_handle* h, const float* xyz, int64_t xyz_stride, c
     HIPCHK(h, h->i_hist.reserve(3 * 2048 * 4));
     HIPCHK(h, h->i_state.reserve(sizeof(SelectState)));
     h->n_blocks = grid_for(n);
-    HIPCHK(h, h->i_partials.reserve((size_t)h->n_blocks * kSums * 8));
+    HIPCHK(h, h->i_partials.reserve((size_t)(grid_for(n * 8) + 8) * kSums * 8));
+    HIPCHK(h, h->i_band.reserve((size_t)kBandCap * kRec * 4));
+    HIPCHK(h, h->i_acc.reserve((size_t)kAccRows * kSums * 8));
     HIPCHK(h, h->i_sums.reserve(kSums * 8));
     HIPCHK(h, h->i_hint.reserve((size_t)n));
     h->s_stride = xyz_stride;
@@ -1475,6 +1942,7 @@ static reg_status prepare_rowmajor(reg_handle* h, const float* T_init_row, const
     }
     HIPCHK(h, hipMemsetAsync(h->i_hint.p, 0, (size_t)n, h->stream));
     HIPCHK(h, hipMemsetAsync(h->i_hist.p, 0, 3 * 2048 * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->i_acc.p, 0, (size_t)kAccRows * kSums * 8, h->stream));
     HIPCHK(h, hipGetLastError());
     h->prepared = true;
     h->have_match = false;
@@ -1505,6 +1973,11 @@ static reg_status init_iter_state(reg_handle* h, const float* T_row, int update)
     st->update = update;
     st->gicp_rot_eps = h->prm.gicp_rot_eps;
     st->gicp_trans_eps = h->prm.gicp_trans_eps;
+    st->band_lo = st->band_hi = INFINITY;
+    st->limit_last = st->limit_prev = INFINITY;
+    st->use_trim = (h->prm.cost == REG_COST_P2PL && h->prm.use_trimmed) ? 1 : 0;
+    st->trim_ratio = h->prm.trim_ratio;
+    st->band_cap = kBandCap;
     HIPCHK(h, hipMemcpyAsync(h->i_iter.p, st, sizeof(IterState), hipMemcpyHostToDevice, h->stream));
     return REG_OK;
 }
@@ -1522,11 +1995,23 @@ static reg_status enqueue_match(reg_handle* h, bool zero_hist = false) {
         k_match<<<h->n_blocks, 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->n, it, h->grid, h->i_pos.as<int>(),
                                                     h->i_d2.as<float>(), hist0, hist2, h->shift0);
     } else {
-        const int blocks = grid_for(h->n * kGroup);
-        k_match_g8<<<blocks, 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->n, it, h->grid, h->i_pos.as<int>(),
-                                                  h->i_d2.as<float>(), hist0, hist2,
-                                                  h->prm.match_variant == 2 ? nullptr : h->i_hint.as<uint8_t>(),
-                                                  h->shift0);
+        uint8_t* hint = h->prm.match_variant == 2 ? nullptr : h->i_hint.as<uint8_t>();
+        if (h->prm.reserved[2] == 4) {  // reserved[2]: lanes per reading point (experiments); default 8
+            const int blocks = grid_for(h->n * 4);
+            k_match_g8<4><<<8 * ((blocks + 7) / 8), 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->n, it, h->grid,
+                                                                          h->i_pos.as<int>(), h->i_d2.as<float>(), hist0,
+                                                                          hist2, hint, h->shift0, h->prm.reserved[0], blocks);
+        } else if (h->prm.reserved[2] == 2) {
+            const int blocks = grid_for(h->n * 2);
+            k_match_g8<2><<<8 * ((blocks + 7) / 8), 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->n, it, h->grid,
+                                                                          h->i_pos.as<int>(), h->i_d2.as<float>(), hist0,
+                                                                          hist2, hint, h->shift0, h->prm.reserved[0], blocks);
+        } else {
+            const int blocks = grid_for(h->n * 8);
+            k_match_g8<8><<<8 * ((blocks + 7) / 8), 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->n, it, h->grid,
+                                                                          h->i_pos.as<int>(), h->i_d2.as<float>(), hist0,
+                                                                          hist2, hint, h->shift0, h->prm.reserved[0], blocks);
+        }
     }
     h->have_match = true;
     return REG_OK;
@@ -1548,17 +2033,13 @@ static reg_status enqueue_select(reg_handle* h) {
     return REG_OK;
 }
 
+static FilterCfg make_filter_cfg(const reg_handle* h, int trim_mode);
+
 static reg_status enqueue_linearize(reg_handle* h, bool want_w, bool limit_from_state = false) {
     float* w = want_w ? h->i_w.as<float>() : nullptr;
     const IterState* it = h->i_iter.as<IterState>();
     if (h->prm.cost == REG_COST_P2PL) {
-        FilterCfg f;
-        f.use_trim = h->prm.use_trimmed ? (limit_from_state ? 1 : 2) : 0;
-        f.use_normal = h->prm.use_surface_normal;
-        f.use_maxdist = h->prm.use_max_dist_filter;
-        f.cos_max_angle = std::cos(h->prm.max_normal_angle);  // cosf in T=float (OutlierFiltersImpl.cpp:229)
-        const float md = h->prm.outlier_max_dist;
-        f.outlier_max_d2 = md * md;
+        const FilterCfg f = make_filter_cfg(h, h->prm.use_trimmed ? (limit_from_state ? 1 : 2) : 0);
         k_linearize_p2pl<<<h->n_blocks, 256, 0, h->stream>>>(
             h->s_xyz.as<float4>(), h->has_snrm ? h->s_nrm.as<float4>() : nullptr, h->n, it, h->i_pos.as<int>(),
             h->i_d2.as<float>(), h->t_pts.as<float4>(), h->t_nrm.as<float4>(), f, h->i_state.as<SelectState>(),
@@ -1572,7 +2053,46 @@ static reg_status enqueue_linearize(reg_handle* h, bool want_w, bool limit_from_
     }
     ++h->seq;
     k_reduce_update<<<1, 1024, 0, h->stream>>>(h->i_partials.as<double>(), h->n_blocks, h->i_iter.as<IterState>(),
-                                               h->d_mirror, h->seq);
+                                               h->d_mirror, h->seq, 0, nullptr, nullptr,
+                                               h->prm.cost == REG_COST_P2PL ? h->i_state.as<SelectState>() : nullptr);
+    return REG_OK;
+}
+
+static FilterCfg make_filter_cfg(const reg_handle* h, int trim_mode) {
+    FilterCfg f;
+    f.use_trim = trim_mode;
+    f.use_normal = h->prm.use_surface_normal;
+    f.use_maxdist = h->prm.use_max_dist_filter;
+    f.debug = h->prm.reserved[0];
+    f.cos_max_angle = std::cos(h->prm.max_normal_angle);  // cosf in T=float (OutlierFiltersImpl.cpp:229)
+    const float md = h->prm.outlier_max_dist;
+    f.outlier_max_d2 = md * md;
+    return f;
+}
+
+// Fused iteration (point-to-plane): search + weights + normal equations in one kernel, band resolution +
+// solve + update in the second.  Two launches per Gauss-Newton iteration.
+template <int G>
+static void launch_fused(reg_handle* h, const FilterCfg& f, float* w, uint8_t* hint) {
+    const int blocks = grid_for(h->n * G);
+    k_iter_fused<G><<<8 * ((blocks + 7) / 8), 256, 0, h->stream>>>(
+        h->s_xyz.as<float4>(), h->has_snrm ? h->s_nrm.as<float4>() : nullptr, h->n, h->i_iter.as<IterState>(), h->grid,
+        h->t_nrm.as<float4>(), f, h->i_pos.as<int>(), h->i_d2.as<float>(), w, hint, h->i_band.as<float>(),
+        h->i_acc.as<double>(), blocks);
+    ++h->seq;
+    k_reduce_update<<<1, 1024, 0, h->stream>>>(h->i_acc.as<double>(), blocks, h->i_iter.as<IterState>(), h->d_mirror,
+                                               h->seq, 1, h->i_band.as<float>(), w, nullptr);
+}
+
+static reg_status enqueue_fused(reg_handle* h, bool want_w) {
+    const FilterCfg f = make_filter_cfg(h, 0);
+    float* w = want_w ? h->i_w.as<float>() : nullptr;
+    uint8_t* hint = h->prm.match_variant == 2 ? nullptr : h->i_hint.as<uint8_t>();
+    if (h->prm.reserved[2] == 4)
+        launch_fused<4>(h, f, w, hint);
+    else
+        launch_fused<8>(h, f, w, hint);
+    h->have_match = true;
     return REG_OK;
 }
 
@@ -1716,29 +2236,73 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
     const unsigned long long seq0 = h->seq;
     const int fixed = h->prm.fixed_iters;
     const int limit = fixed > 0 ? fixed : h->prm.max_iter;
-    constexpr int kAhead = 2;
-    int enq = 0;
+    // Iterations 0..kGenericFirst-1 run on the generic (select-based) path: the trimmed limit still moves too
+    // much to be predicted.  Afterwards the fused two-kernel iteration is used; if its band prediction fails the
+    // device stalls the queue and the host repairs that iteration on the generic path.
+    const bool can_fuse = p2pl && h->prm.reserved[3] != 1;
+    const bool trimming = p2pl && h->prm.use_trimmed && h->prm.trim_ratio != 1.0f;
+    const int kGenericFirst = trimming ? 2 : 1;
+    const int kAhead = fixed > 0 ? 4 : 2;
     const HostMirror* mir = h->h_mirror;
+    int generic_left = kGenericFirst;
+    const bool trace = getenv("O3D_TRACE") != nullptr;
+    unsigned long long last_traced = 0;
+    unsigned long long acked = seq0;   // every sequence <= acked has either reported or been a no-op
+    int stalls = 0;
     for (;;) {
-        const unsigned long long seen_seq = mirror_seq(h);
-        const int seen = seen_seq > seq0 ? (int)(seen_seq - seq0) : 0;
-        const bool done = seen > 0 && mir->done;
-        if (done || (seen >= limit)) break;
-        if (enq < limit && (fixed > 0 || enq - seen < kAhead)) {
-            s = enqueue_iteration(h, false);
-            if (s != REG_OK) return s;
-            ++enq;
+        const unsigned long long m_seq = std::max(mirror_seq(h), seq0);
+        const bool any = m_seq > seq0;
+        if (any && mir->done) break;
+        if (any && mir->stall && m_seq > acked) {
+            // band prediction failed at sequence m_seq: everything enqueued behind it is a no-op; drain, repair
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            acked = h->seq;
+            generic_left = 2;
+            ++stalls;
             continue;
         }
-        if (enq == seen) break;  // nothing in flight and nothing left to enqueue
-        s = wait_seq(h, seq0 + (unsigned long long)seen + 1);
+        if (trace && m_seq != last_traced) {
+            last_traced = m_seq;
+            fprintf(stderr, "[o3dreg] seq %llu iter %d stall %d band_n %d limit %.6g prev %.6g band [%.6g, %.6g)\n",
+                    m_seq - seq0, mir->iterations, mir->stall, mir->stall ? mir->band_count : mir->pad_nband, mir->limit_last, mir->limit_prev,
+                    mir->band_lo, mir->band_hi);
+        }
+        acked = std::max(acked, m_seq);
+        const int completed = any ? mir->iterations : 0;
+        const int inflight = (int)(h->seq - acked);
+        if (completed + inflight < limit && inflight < kAhead) {
+            // fuse only once the trimmed limit has settled (last two seen limits within 5 %): the band is then
+            // narrow (few hundred records) and the prediction practically never fails
+            bool settled = true;
+            if (trimming) {
+                settled = any && mir->limit_prev < INFINITY && mir->limit_last < INFINITY &&
+                          std::fabs(mir->limit_last - mir->limit_prev) <= 0.05f * mir->limit_last;
+            }
+            if (!can_fuse || generic_left > 0 || !settled) {
+                s = enqueue_iteration(h, false);
+                if (generic_left > 0) --generic_left;
+            } else {
+                s = enqueue_fused(h, false);
+            }
+            if (s != REG_OK) return s;
+            continue;
+        }
+        if (inflight == 0) break;  // nothing in flight and nothing left to enqueue
+        s = wait_seq(h, acked + 1);
         if (s != REG_OK) return s;
-        if (mirror_seq(h) < seq0 + (unsigned long long)seen + 1) break;  // stream drained: remaining work was no-ops
+        if (mirror_seq(h) <= acked) {
+            // the stream drained without a report: the remaining sequences were no-ops (done or stalled earlier)
+            if (hipStreamQuery(h->stream) == hipSuccess && mirror_seq(h) <= acked) acked = h->seq;
+        }
     }
+    h->last_stalls = stalls;
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipEventSynchronize(h->ev1));
     HIPCHK(h, hipGetLastError());
     (void)hipEventElapsedTime(&res->loop_ms, h->ev0, h->ev1);
+    if (getenv("O3D_STAMPS"))
+        fprintf(stderr, "update kernel stamps (cycles): reduce %llu [rows %llu select %llu band-add %llu] solve %llu update+check %llu mirror %llu\n", mir->stamps[0],
+                mir->stamps[4], mir->stamps[5], mir->stamps[6], mir->stamps[1], mir->stamps[2], mir->stamps[3]);
     res->iterations = mir->iterations;
     res->converged = mir->converged;
     res->max_iter_reached = mir->max_iter_reached;
@@ -1754,6 +2318,7 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
     compose_rowmajor(h, T_iter, Tout_row);
     row_to_col(T_iter, res->T_iter_last);
     row_to_col(Tout_row, T_out);
+    res->n_band_stalls = h->last_stalls;
     return REG_OK;
 }
 

@@ -42,6 +42,16 @@ struct Grid {
     float rho[kMaxLevels];       // search radii; the last one is max_dist (or +inf)
     float rho_box[kMaxLevels];   // radius used for the bin box (rho + safety margin)
     float max_d2;                // fl(max_dist*max_dist) (+inf allowed)
+    // Level-0 accelerator ("halo bins"): a dense grid of bins of edge c_h; bin B lists every reference point
+    // inside B's box grown by rho_h on each side, contiguously, as {x, y, z, bits(sorted position)}.  A query
+    // in bin B therefore finds every point within rho_h in ONE contiguous run (no neighbour-bin lookups).
+    int use_halo;
+    float hox, hoy, hoz, hinv_c;
+    int hdimx, hdimy, hdimz;
+    const uint32_t* halo_start;  // [hdimx*hdimy*hdimz + 1]
+    const float4* halo_pts;
+    float rho_h;                 // exactness radius of the halo level
+    int level_after_halo;        // first regular level with rho > rho_h
 };
 
 struct Xf {  // row-major 3x4
@@ -171,7 +181,7 @@ __device__ __forceinline__ Best nearest(const Grid& g, float3 p) {
 // and the group's best candidate is combined with three xor-shuffles.  All lanes of a group take the
 // same control flow, so divergence is limited to the 8 groups of a wave.
 // -------------------------------------------------------------------------------------------------
-constexpr int kGroup = 8;
+constexpr int kGroup = 8;   // default group width (lanes per reading point); kernels are templated on it
 
 __device__ __forceinline__ void consider(const Grid& g, float3 p, const float4 t, int j, Best& best) {
     const float dx = p.x - t.x, dy = p.y - t.y, dz = p.z - t.z;
@@ -199,9 +209,10 @@ __device__ __forceinline__ void scan_run(const Grid& g, float3 p, uint32_t s, ui
     }
 }
 
+template <int G>
 __device__ __forceinline__ Best group_min(Best b) {
 #pragma unroll
-    for (int m = 1; m < kGroup; m <<= 1) {
+    for (int m = 1; m < G; m <<= 1) {
         const float od2 = __shfl_xor(b.d2, m);
         const uint32_t oidx = __shfl_xor(b.idx, m);
         const int opos = __shfl_xor(b.pos, m);
@@ -214,6 +225,64 @@ __device__ __forceinline__ Best group_min(Best b) {
     return b;
 }
 
+// Candidate from a halo record {x, y, z, bits(sorted position)}.  The original index (tie-break) is only
+// fetched when two candidates are exactly equidistant.
+__device__ __forceinline__ void consider_pos(const Grid& g, float3 p, const float4 t, Best& best) {
+    const float dx = p.x - t.x, dy = p.y - t.y, dz = p.z - t.z;
+    float a = dx * dx;
+    float b = dy * dy;
+    float d2 = a + b;
+    a = dz * dz;
+    d2 = d2 + a;
+    const int pos = (int)__float_as_uint(t.w);
+    if (d2 <= g.max_d2) {
+        if (d2 < best.d2) {
+            best.d2 = d2;
+            best.pos = pos;
+            best.idx = 0xffffffffu;  // not fetched
+        } else if (d2 == best.d2 && pos != best.pos) {
+            if (best.idx == 0xffffffffu) best.idx = __float_as_uint(g.pts[best.pos].w);
+            const uint32_t idx = __float_as_uint(g.pts[pos].w);
+            if (idx < best.idx) {
+                best.idx = idx;
+                best.pos = pos;
+            }
+        }
+    }
+}
+
+// Group minimum of (d2, original index) where idx may not have been fetched yet (0xffffffff).
+template <int G>
+__device__ __forceinline__ Best group_min_lazy(const Grid& g, Best b, int gbase) {
+    float m = b.d2;
+#pragma unroll
+    for (int k = 1; k < G; k <<= 1) m = fminf(m, __shfl_xor(m, k));
+    const bool cand = b.pos >= 0 && b.d2 == m;
+    const unsigned mask = (unsigned)((__ballot(cand) >> gbase) & ((1ull << G) - 1ull));
+    Best r;
+    r.d2 = INFINITY;
+    r.idx = 0xffffffffu;
+    r.pos = -1;
+    if (mask == 0) return r;
+    if ((mask & (mask - 1)) == 0) {  // exactly one lane holds the minimum
+        r.d2 = m;
+        r.pos = __shfl(b.pos, gbase + __ffs((int)mask) - 1);
+        r.idx = (uint32_t)__shfl((int)b.idx, gbase + __ffs((int)mask) - 1);
+        return r;
+    }
+    // tie between lanes: lowest original index wins
+    uint32_t idx = 0xffffffffu;
+    if (cand) idx = b.idx != 0xffffffffu ? b.idx : __float_as_uint(g.pts[b.pos].w);
+    uint32_t mi = idx;
+#pragma unroll
+    for (int k = 1; k < G; k <<= 1) mi = min(mi, (uint32_t)__shfl_xor((int)mi, k));
+    const unsigned win = (unsigned)((__ballot(cand && idx == mi) >> gbase) & ((1ull << G) - 1ull));
+    r.d2 = m;
+    r.idx = mi;
+    r.pos = __shfl(b.pos, gbase + __ffs((int)win) - 1);
+    return r;
+}
+
 // `sub` = lane index inside the group (0..7); `first_level` lets the caller skip radii that were too
 // small for this query in the previous iteration (any starting level is exact).  Returns the level at
 // which the search terminated through *level_out.
@@ -222,13 +291,44 @@ __device__ __forceinline__ Best group_min(Best b) {
 // each lane of the group looks up one segment (brick hash probe + two bin-start loads).  Phase 2: the
 // group scans every non-empty segment TOGETHER, lane k reading point s+k, s+k+8, ... -- consecutive
 // 16-byte records, i.e. one or two cache lines per group step instead of one line per lane.
+template <int G>
 __device__ __forceinline__ Best nearest_group(const Grid& g, float3 p, int sub, int first_level, int* level_out) {
     Best best;
     best.d2 = INFINITY;
     best.idx = 0xffffffffu;
     best.pos = -1;
-    const int gbase = (int)(threadIdx.x & 63) & ~(kGroup - 1);  // first lane of this group in the wave
+    const int gbase = (int)(threadIdx.x & 63) & ~(G - 1);  // first lane of this group in the wave
     int l = min(first_level, g.n_levels - 1);
+    if (g.use_halo && first_level < 0) {
+        // halo level: one dense-grid lookup, one contiguous run
+        const float fx = bin_coord_f(p.x, g.hox, g.hinv_c), fy = bin_coord_f(p.y, g.hoy, g.hinv_c),
+                    fz = bin_coord_f(p.z, g.hoz, g.hinv_c);
+        const bool inside = fx >= 0.f && fy >= 0.f && fz >= 0.f && fx < (float)g.hdimx && fy < (float)g.hdimy &&
+                            fz < (float)g.hdimz;
+        l = 0;
+        if (inside) {
+            const size_t B = ((size_t)(int)fz * g.hdimy + (int)fy) * g.hdimx + (int)fx;
+            const uint32_t s = g.halo_start[B], e = g.halo_start[B + 1];
+            constexpr int kU = 4;
+            for (uint32_t j0 = s; j0 < e; j0 += kU * G) {
+                float4 tv[kU];
+#pragma unroll
+                for (int u = 0; u < kU; ++u) tv[u] = g.halo_pts[min(j0 + (uint32_t)(u * G + sub), e - 1)];
+#pragma unroll
+                for (int u = 0; u < kU; ++u) consider_pos(g, p, tv[u], best);
+            }
+            best = group_min_lazy<G>(g, best, gbase);
+            const float rh = g.rho_h;
+            const float rh2 = rh * rh;
+            if (best.pos >= 0 && best.d2 <= rh2) {
+                *level_out = -1;
+                return best;
+            }
+            if (best.pos >= 0 && best.idx == 0xffffffffu) best.idx = __float_as_uint(g.pts[best.pos].w);
+            l = g.level_after_halo;
+        }
+    }
+    l = max(l, 0);
     for (; l < g.n_levels; ++l) {
         const float rb = g.rho_box[l];
         const int lox = (int)fminf(fmaxf(bin_coord_f(p.x - rb, g.ox, g.inv_c), 0.f), g.dimx - 1.f);
@@ -242,7 +342,7 @@ __device__ __forceinline__ Best nearest_group(const Grid& g, float3 p, int sub, 
         const int nbx = (hix >> kBrickLog2) - bx0 + 1;
         const int nrow = nbx * ny;
         const int total = nrow * nz;
-        for (int base = 0; base < total; base += kGroup) {
+        for (int base = 0; base < total; base += G) {
             // phase 1: one segment per lane
             uint32_t s = 0, e = 0;
             const int t = base + sub;
@@ -268,28 +368,28 @@ __device__ __forceinline__ Best nearest_group(const Grid& g, float3 p, int sub, 
             const uint32_t cnt = e - s;
             uint32_t incl = cnt;
 #pragma unroll
-            for (int o = 1; o < kGroup; o <<= 1) {
+            for (int o = 1; o < G; o <<= 1) {
                 const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
                 if (sub >= o) incl += v;
             }
-            const uint32_t total_pts = (uint32_t)__shfl((int)incl, gbase + kGroup - 1);
+            const uint32_t total_pts = (uint32_t)__shfl((int)incl, gbase + G - 1);
             if (total_pts == 0) continue;
-            uint32_t ex[kGroup], st[kGroup];
+            uint32_t ex[G], st[G];
 #pragma unroll
-            for (int k = 0; k < kGroup; ++k) {
+            for (int k = 0; k < G; ++k) {
                 ex[k] = (uint32_t)__shfl((int)(incl - cnt), gbase + k);
                 st[k] = (uint32_t)__shfl((int)s, gbase + k);
             }
             constexpr int kUnroll = 4;
-            for (uint32_t f0 = 0; f0 < total_pts; f0 += kUnroll * kGroup) {
+            for (uint32_t f0 = 0; f0 < total_pts; f0 += kUnroll * G) {
                 float4 tv[kUnroll];
                 uint32_t jv[kUnroll];
 #pragma unroll
                 for (int u = 0; u < kUnroll; ++u) {
-                    const uint32_t f = min(f0 + (uint32_t)(u * kGroup + sub), total_pts - 1);  // clamp: duplicates are harmless
+                    const uint32_t f = min(f0 + (uint32_t)(u * G + sub), total_pts - 1);  // clamp: duplicates are harmless
                     uint32_t base_pt = st[0], base_f = 0;
 #pragma unroll
-                    for (int k = 1; k < kGroup; ++k)
+                    for (int k = 1; k < G; ++k)
                         if (f >= ex[k]) {
                             base_pt = st[k];
                             base_f = ex[k];
@@ -301,7 +401,7 @@ __device__ __forceinline__ Best nearest_group(const Grid& g, float3 p, int sub, 
                 for (int u = 0; u < kUnroll; ++u) consider(g, p, tv[u], (int)jv[u], best);
             }
         }
-        best = group_min(best);
+        best = group_min<G>(best);
         const float r = g.rho[l];
         const float r2 = r * r;
         if (best.pos >= 0 && best.d2 <= r2) break;  // every point within rho was inside the box: exact
