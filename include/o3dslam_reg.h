@@ -87,8 +87,14 @@ typedef struct {
     float   cell_size;          /* voxel-bin edge in metres; 0 = choose from target density */
     int32_t device;             /* HIP device ordinal */
     int32_t sort_source;        /* 1: Morton-order the reading on upload (speed only; results in input order) */
+    int32_t profile_loop;       /* 1: bracket every search kernel of reg_register with HIP events (perturbs the loop slightly) */
     int32_t match_variant;      /* 0: 8 lanes per reading point + level hints (default); 1: one lane per point; 2: 8 lanes, no hints; 3: as 0 with the level-0 histogram fused into the match kernel */
-    int32_t reserved[6];
+    /* experiment switches (all 0 in production; used by the A/B scripts under tools/) */
+    int32_t debug_flags;        /* kernel ablation bits (timing experiments only; results are wrong when set) */
+    int32_t disable_halo;       /* 1: no halo-bin level 0 */
+    int32_t lanes_per_point;    /* 0 = default (8); 4 */
+    int32_t disable_fused;      /* 1: every iteration on the generic (select-based) path */
+    int32_t reserved[1];
 } reg_params;
 
 typedef struct {
@@ -108,6 +114,8 @@ typedef struct {
     float   T_iter_last[16];    /* final T_iter (column-major): P2PL in the centred frames, GICP == T_out */
     int32_t n_band_stalls;      /* fused path: iterations whose trimmed-band prediction failed and were re-run on the generic path */
     int32_t reserved;
+    float   prof_ms[4];         /* params.profile_loop: summed device time (HIP events) of [0] k_match, [1] k_iter_fused launches */
+    int32_t prof_launches[4];   /* ... and how many launches that was */
 } reg_result;
 
 /* ICPChainBase::setDefault (ICP.cpp:100-113): knn 1, eps 0, maxDist inf, Trimmed 0.85,

@@ -32,7 +32,8 @@ class RegParams(C.Structure):
                 ("min_diff_rot", C.c_float), ("min_diff_trans", C.c_float), ("smooth_len", C.c_int32),
                 ("fixed_iters", C.c_int32), ("gicp_rot_eps", C.c_float), ("gicp_trans_eps", C.c_float),
                 ("cell_size", C.c_float), ("device", C.c_int32), ("sort_source", C.c_int32),
-                ("match_variant", C.c_int32), ("reserved", C.c_int32 * 6)]
+                ("profile_loop", C.c_int32), ("match_variant", C.c_int32), ("debug_flags", C.c_int32), ("disable_halo", C.c_int32),
+                ("lanes_per_point", C.c_int32), ("disable_fused", C.c_int32), ("reserved", C.c_int32 * 1)]
 
 
 class RegResult(C.Structure):
@@ -40,7 +41,8 @@ class RegResult(C.Structure):
                 ("rank_last", C.c_int32), ("n_inliers", C.c_int64), ("n_matched", C.c_int64), ("error", C.c_double),
                 ("fitness", C.c_double), ("inlier_rmse", C.c_double), ("H_last", C.c_float * 36),
                 ("b_last", C.c_float * 6), ("target_build_ms", C.c_float), ("loop_ms", C.c_float),
-                ("T_iter_last", C.c_float * 16), ("n_band_stalls", C.c_int32), ("reserved", C.c_int32)]
+                ("T_iter_last", C.c_float * 16), ("n_band_stalls", C.c_int32), ("reserved", C.c_int32),
+                ("prof_ms", C.c_float * 4), ("prof_launches", C.c_int32 * 4)]
 
 
 class TargetInfo(C.Structure):

@@ -842,6 +842,9 @@ k_linearize_gicp(const float4* __restrict__ src, const float4* __restrict__ src_
 constexpr int kBandCap = 16384;
 constexpr int kAccRows = 64;   // replicas of the 32-double accumulator (spreads the fp64 atomics)
 constexpr int kRec = 32;   // floats per band record
+// Band buffer layout: record-major band[slot][kRec] (component-major, with or without a padded pitch, measured
+// 2x slower for the single-workgroup reader: 19.5k vs 5.9k cycles for the add phase at 600 records)
+__host__ __device__ __forceinline__ size_t band_at(int comp, size_t slot) { return slot * kRec + (size_t)comp; }
 
 // products for one reading point: vals[0..20] = F_a F_c (upper triangle), [21..26] = F_a r, [27] = r^2
 __device__ __forceinline__ void p2pl_products(float3 p, float4 q, float4 nn, float w, float* vals) {
@@ -933,11 +936,11 @@ k_iter_fused(const float4* __restrict__ src, const float4* __restrict__ src_nrm,
                 // band record: decided by the update kernel
                 const unsigned slot = atomicAdd(&it->band_count, 1u);
                 if (slot < (unsigned)kBandCap) {
-                    float* rec = band + (size_t)slot * kRec;
 #pragma unroll
-                    for (int k = 0; k < 31; ++k) rec[k] = vals[k];
-                    rec[29] = dd;                            // [29] = d2 (the "matched" count is added from cls below)
-                    rec[31] = __int_as_float((int)q);
+                    for (int k = 0; k < 31; ++k)
+                        if (k != 29) band[band_at(k, slot)] = vals[k];
+                    band[band_at(29, slot)] = dd;   // [29] = d2 (the "matched" count is added from cls below)
+                    band[band_at(31, slot)] = __int_as_float((int)q);
                 }
             }
         }
@@ -1028,6 +1031,8 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
     __shared__ uint32_t pick[2];
     __shared__ float s_limit;
     __shared__ uint32_t bd2[kBandCap];
+    __shared__ uint32_t small[64];
+    __shared__ uint32_t s_cnt;
     if (it->done) return;
     if (fused && it->stall) return;
     const unsigned long long st0 = __builtin_amdgcn_s_memtime();
@@ -1075,9 +1080,51 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
             return;
         }
         if (n_finite != 0) {
-            // stage the band's d2 bit patterns in LDS once; the three radix levels then run out of LDS
-            for (uint32_t i = threadIdx.x; i < n_band; i += 1024) bd2[i] = __float_as_uint(band[(size_t)i * kRec + 29]);
+            // stage the band's d2 bit patterns in LDS once; issue this thread's share of the record loads NOW
+            // (they do not depend on the limit) so their latency hides behind the select
+            for (uint32_t i = threadIdx.x; i < n_band; i += 1024) bd2[i] = __float_as_uint(band[band_at(29, i)]);
+            float pre[16];
+            const bool add_comp = comp != 29 && comp != 31;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const uint32_t i = min((uint32_t)part + 32u * u, n_band - 1);
+                pre[u] = add_comp ? band[band_at(comp, i)] : 0.f;
+            }
+            // One-level select: the band's values lie in [band_lo, band_hi), so the order-preserving key
+            // (u - u_lo) * 2048 / (u_hi - u_lo) spreads them over 2048 bins (about one value per bin); the bin that
+            // holds rank r is then resolved by direct ranking.  Crowded bin (> 64 equal-ish values): radix levels.
+            const uint32_t u_lo = __float_as_uint(it->band_lo), u_hi = __float_as_uint(it->band_hi);
+            const uint64_t span = (uint64_t)(u_hi > u_lo ? u_hi - u_lo : 1u);
             uint32_t rank = k - n_below, prefix = 0;
+            for (int i = threadIdx.x; i < 2048; i += 1024) hist[i] = 0;
+            if (threadIdx.x == 0) s_cnt = 0;
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < n_band; i += 1024) {
+                const uint32_t key = (uint32_t)(((uint64_t)(bd2[i] - u_lo) * 2048ull) / span);
+                atomicAdd(&hist[min(key, 2047u)], 1u);
+            }
+            __syncthreads();
+            block_pick1024(hist, 2048, rank, wave_tot, pick);
+            const uint32_t bsel = pick[0], rsel = pick[1], csel = hist[pick[0]];
+            __syncthreads();
+            if (csel <= 64u) {
+                for (uint32_t i = threadIdx.x; i < n_band; i += 1024) {
+                    const uint32_t key = min((uint32_t)(((uint64_t)(bd2[i] - u_lo) * 2048ull) / span), 2047u);
+                    if (key == bsel) small[atomicAdd(&s_cnt, 1u)] = bd2[i];
+                }
+                __syncthreads();
+                if (threadIdx.x < csel) {
+                    const uint32_t e = small[threadIdx.x];
+                    uint32_t r = 0;
+                    for (uint32_t j = 0; j < csel; ++j) {
+                        const uint32_t o = small[j];
+                        r += (o < e || (o == e && j < threadIdx.x)) ? 1u : 0u;
+                    }
+                    if (r == rsel) s_limit = __uint_as_float(e);
+                }
+                __syncthreads();
+                prefix = __float_as_uint(s_limit);
+            } else {
             for (int level = 0; level < 3; ++level) {
                 for (int i = threadIdx.x; i < 2048; i += 1024) hist[i] = 0;
                 __syncthreads();
@@ -1093,20 +1140,25 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
                 rank = pick[1];
                 __syncthreads();
             }
+            }
             if (threadIdx.x == 0) s_limit = __uint_as_float(prefix);
             __syncthreads();
             stB = __builtin_amdgcn_s_memtime();
             const float limit = s_limit;
             // ---- add the band records that survive the trim (component-wise, 32 parts)
-            // (8 records in flight per thread: a dependent load per record would cost a memory latency each)
             double acc = 0;
-            if (comp != 29 && comp != 31)
-                for (uint32_t i0 = part; i0 < n_band; i0 += 32 * 16) {
+            if (add_comp) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const uint32_t i = (uint32_t)part + 32u * u;
+                    if (i < n_band && __uint_as_float(bd2[i]) <= limit) acc += (double)pre[u];
+                }
+                for (uint32_t i0 = part + 32u * 16u; i0 < n_band; i0 += 32 * 16) {   // only when n_band > 512
                     float vv[16];
 #pragma unroll
                     for (int u = 0; u < 16; ++u) {
                         const uint32_t i = min(i0 + 32u * u, n_band - 1);
-                        vv[u] = band[(size_t)i * kRec + comp];
+                        vv[u] = band[band_at(comp, i)];
                     }
 #pragma unroll
                     for (int u = 0; u < 16; ++u) {
@@ -1114,11 +1166,11 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
                         if (i < n_band && __uint_as_float(bd2[i]) <= limit) acc += (double)vv[u];
                     }
                 }
+            }
             sh[part][comp] = acc;
             if (w_out)
                 for (uint32_t i = threadIdx.x; i < n_band; i += 1024) {
-                    const float* rec = band + (size_t)i * kRec;
-                    if (!(__uint_as_float(bd2[i]) <= limit)) w_out[__float_as_int(rec[31])] = 0.f;
+                    if (!(__uint_as_float(bd2[i]) <= limit)) w_out[__float_as_int(band[band_at(31, i)])] = 0.f;
                 }
             __syncthreads();
             if (threadIdx.x < kSums) {
@@ -1325,6 +1377,10 @@ struct reg_handle {
     DevBuf i_hint, s_keys, s_keys2, s_perm, s_perm2, s_tmp, i_tmpf;
     const uint32_t* perm = nullptr;   // slot -> input index (null: identity)
     int last_stalls = 0;
+    // loop profiling (params.profile_loop): HIP events around the search kernels of every iteration
+    std::vector<hipEvent_t> prof_ev;   // pairs (start, stop)
+    std::vector<int> prof_kind;        // 0: k_match, 1: k_iter_fused
+    bool profiling = false;
     int shift0 = 21;                  // low bit of the level-0 radix digit (19 when max_dist^2 < 2: bits 31,30 are 0)
     int n_blocks = 0;
     bool have_match = false;
@@ -1601,7 +1657,7 @@ static reg_status build_halo(reg_handle* h, float c, const float bmin[3], const 
     Grid& g = h->grid;
     g.use_halo = 0;
     g.level_after_halo = 0;
-    if (h->prm.reserved[1] == 1) return REG_OK;  // reserved[1] == 1: halo level disabled (A/B experiments)
+    if (h->prm.disable_halo == 1) return REG_OK;  // A/B experiments
     const float ch = 1.5f * c;
     const float abs_margin = 4e-7f * (1.0f + max_abs);
     const float rho_h = 0.25f * ch * (1.0f - 4e-3f) - 2.f * abs_margin;
@@ -1984,6 +2040,15 @@ static reg_status init_iter_state(reg_handle* h, const float* T_row, int update)
 
 // R3+R4.  Buffer hygiene of the trimmed-quantile histograms needs no memset launches: the match kernel
 // zeroes hist2, the level-2 select kernel zeroes hist0, the linearize kernel zeroes hist1.
+static void prof_mark(reg_handle* h, int kind, bool start) {
+    if (!h->profiling) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, h->stream);
+    h->prof_ev.push_back(e);
+    if (start) h->prof_kind.push_back(kind);
+}
+
 static reg_status enqueue_match(reg_handle* h, bool zero_hist = false) {
     const bool trim = h->prm.cost == REG_COST_P2PL && h->prm.use_trimmed;
     if (trim && zero_hist) HIPCHK(h, hipMemsetAsync(h->i_hist.p, 0, 3 * 2048 * 4, h->stream));
@@ -1991,28 +2056,30 @@ static reg_status enqueue_match(reg_handle* h, bool zero_hist = false) {
     uint32_t* hist0 = (trim && fused_hist) ? h->i_hist.as<uint32_t>() : nullptr;
     uint32_t* hist2 = trim ? h->i_hist.as<uint32_t>() + 4096 : nullptr;
     const IterState* it = h->i_iter.as<IterState>();
+    prof_mark(h, 0, true);
     if (h->prm.match_variant == 1) {
         k_match<<<h->n_blocks, 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->n, it, h->grid, h->i_pos.as<int>(),
                                                     h->i_d2.as<float>(), hist0, hist2, h->shift0);
     } else {
         uint8_t* hint = h->prm.match_variant == 2 ? nullptr : h->i_hint.as<uint8_t>();
-        if (h->prm.reserved[2] == 4) {  // reserved[2]: lanes per reading point (experiments); default 8
+        if (h->prm.lanes_per_point == 4) {
             const int blocks = grid_for(h->n * 4);
             k_match_g8<4><<<8 * ((blocks + 7) / 8), 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->n, it, h->grid,
                                                                           h->i_pos.as<int>(), h->i_d2.as<float>(), hist0,
-                                                                          hist2, hint, h->shift0, h->prm.reserved[0], blocks);
-        } else if (h->prm.reserved[2] == 2) {
+                                                                          hist2, hint, h->shift0, h->prm.debug_flags, blocks);
+        } else if (h->prm.lanes_per_point == 2) {
             const int blocks = grid_for(h->n * 2);
             k_match_g8<2><<<8 * ((blocks + 7) / 8), 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->n, it, h->grid,
                                                                           h->i_pos.as<int>(), h->i_d2.as<float>(), hist0,
-                                                                          hist2, hint, h->shift0, h->prm.reserved[0], blocks);
+                                                                          hist2, hint, h->shift0, h->prm.debug_flags, blocks);
         } else {
             const int blocks = grid_for(h->n * 8);
             k_match_g8<8><<<8 * ((blocks + 7) / 8), 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->n, it, h->grid,
                                                                           h->i_pos.as<int>(), h->i_d2.as<float>(), hist0,
-                                                                          hist2, hint, h->shift0, h->prm.reserved[0], blocks);
+                                                                          hist2, hint, h->shift0, h->prm.debug_flags, blocks);
         }
     }
+    prof_mark(h, 0, false);
     h->have_match = true;
     return REG_OK;
 }
@@ -2063,7 +2130,7 @@ static FilterCfg make_filter_cfg(const reg_handle* h, int trim_mode) {
     f.use_trim = trim_mode;
     f.use_normal = h->prm.use_surface_normal;
     f.use_maxdist = h->prm.use_max_dist_filter;
-    f.debug = h->prm.reserved[0];
+    f.debug = h->prm.debug_flags;
     f.cos_max_angle = std::cos(h->prm.max_normal_angle);  // cosf in T=float (OutlierFiltersImpl.cpp:229)
     const float md = h->prm.outlier_max_dist;
     f.outlier_max_d2 = md * md;
@@ -2075,10 +2142,12 @@ static FilterCfg make_filter_cfg(const reg_handle* h, int trim_mode) {
 template <int G>
 static void launch_fused(reg_handle* h, const FilterCfg& f, float* w, uint8_t* hint) {
     const int blocks = grid_for(h->n * G);
+    prof_mark(h, 1, true);
     k_iter_fused<G><<<8 * ((blocks + 7) / 8), 256, 0, h->stream>>>(
         h->s_xyz.as<float4>(), h->has_snrm ? h->s_nrm.as<float4>() : nullptr, h->n, h->i_iter.as<IterState>(), h->grid,
         h->t_nrm.as<float4>(), f, h->i_pos.as<int>(), h->i_d2.as<float>(), w, hint, h->i_band.as<float>(),
         h->i_acc.as<double>(), blocks);
+    prof_mark(h, 1, false);
     ++h->seq;
     k_reduce_update<<<1, 1024, 0, h->stream>>>(h->i_acc.as<double>(), blocks, h->i_iter.as<IterState>(), h->d_mirror,
                                                h->seq, 1, h->i_band.as<float>(), w, nullptr);
@@ -2088,7 +2157,7 @@ static reg_status enqueue_fused(reg_handle* h, bool want_w) {
     const FilterCfg f = make_filter_cfg(h, 0);
     float* w = want_w ? h->i_w.as<float>() : nullptr;
     uint8_t* hint = h->prm.match_variant == 2 ? nullptr : h->i_hint.as<uint8_t>();
-    if (h->prm.reserved[2] == 4)
+    if (h->prm.lanes_per_point == 4)
         launch_fused<4>(h, f, w, hint);
     else
         launch_fused<8>(h, f, w, hint);
@@ -2232,6 +2301,7 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
         std::memcpy(T_start, Ti, 64);
     s = init_iter_state(h, T_start, 1);
     if (s != REG_OK) return s;
+    h->profiling = h->prm.profile_loop != 0;
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     const unsigned long long seq0 = h->seq;
     const int fixed = h->prm.fixed_iters;
@@ -2239,7 +2309,7 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
     // Iterations 0..kGenericFirst-1 run on the generic (select-based) path: the trimmed limit still moves too
     // much to be predicted.  Afterwards the fused two-kernel iteration is used; if its band prediction fails the
     // device stalls the queue and the host repairs that iteration on the generic path.
-    const bool can_fuse = p2pl && h->prm.reserved[3] != 1;
+    const bool can_fuse = p2pl && h->prm.disable_fused != 1;
     const bool trimming = p2pl && h->prm.use_trimmed && h->prm.trim_ratio != 1.0f;
     const int kGenericFirst = trimming ? 2 : 1;
     const int kAhead = fixed > 0 ? 4 : 2;
@@ -2303,6 +2373,20 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
     if (getenv("O3D_STAMPS"))
         fprintf(stderr, "update kernel stamps (cycles): reduce %llu [rows %llu select %llu band-add %llu] solve %llu update+check %llu mirror %llu\n", mir->stamps[0],
                 mir->stamps[4], mir->stamps[5], mir->stamps[6], mir->stamps[1], mir->stamps[2], mir->stamps[3]);
+    if (h->profiling) {
+        for (size_t i = 0; i + 1 < h->prof_ev.size(); i += 2) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, h->prof_ev[i], h->prof_ev[i + 1]) == hipSuccess) {
+                const int kind = h->prof_kind[i / 2];
+                res->prof_ms[kind] += ms;
+                res->prof_launches[kind] += 1;
+            }
+        }
+        for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
+        h->prof_ev.clear();
+        h->prof_kind.clear();
+        h->profiling = false;
+    }
     res->iterations = mir->iterations;
     res->converged = mir->converged;
     res->max_iter_reached = mir->max_iter_reached;

@@ -289,3 +289,48 @@ def test_cpp_mirror_demo_runs():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "OK" in out.stdout
+
+
+def test_distributed_halves_on_one_gpu_match_the_fused_loop():
+    """The entry points the multi-GPU driver uses (reg_source_centroid_sums / reg_prepare_centroid /
+    reg_match_local / reg_trim_histogram / reg_reduce_local / reg_solve_update / reg_compose) reproduce
+    reg_register when driven by DistributedRegistration with a single rank."""
+    from open3d_slam_private_amd.distributed import DistributedRegistration
+    sc = synth.make_scene(10000, 100000, seed=31)
+    p = capi.shipped_params()
+    p.fixed_iters = 8
+    reg = capi.Registration(p)
+    reg.set_target(sc.tgt_xyz, sc.tgt_nrm)
+    reg.set_source(sc.src_xyz, sc.src_nrm)
+    T_ref, res = reg.register(np.eye(4))
+    # two "ranks" = two handles on the same GPU, each with half of the reading; sums added by hand
+    n = sc.src_xyz.shape[0]
+    halves = []
+    for lo, hi in ((0, n // 2), (n // 2, n)):
+        r = capi.Registration(p)
+        r.set_target(sc.tgt_xyz, sc.tgt_nrm)
+        r.set_source(sc.src_xyz[lo:hi], sc.src_nrm[lo:hi])
+        halves.append(r)
+    sums = sum(r.source_centroid_sums() for r in halves)
+    c = (sums.astype(np.float64) / (65536.0 * n)).astype(np.float32)
+    assert np.array_equal(c, orc.centroid(sc.src_xyz))
+    for r in halves:
+        r.prepare_centroid(np.eye(4), c)
+
+    class Both:
+        def match_local(self, T):
+            for r in halves:
+                r.match_local(T)
+
+        def trim_histogram(self, level, prefix):
+            return sum(r.trim_histogram(level, prefix).astype(np.int64) for r in halves)
+
+        def reduce_local(self, T, limit):
+            return sum(r.reduce_local(T, limit) for r in halves)
+
+    dreg = DistributedRegistration(Both(), lambda s, T: capi.solve_update(p, s, T)[0], True, p.trim_ratio, 8)
+    T_iter, sums = dreg.run()
+    T = halves[0].compose(T_iter)
+    dt, dr = synth.pose_error(T, T_ref)
+    assert dt <= 1e-6 and dr <= 1e-6, (dt, dr)
+    assert int(round(sums[28])) == res.n_inliers

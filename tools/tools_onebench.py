@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Run a few registrations + kernel profiling passes with one configuration (for rocprofv3 --pmc runs)."""
 import sys, numpy as np
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from open3d_slam_private_amd import capi, synth
 n_src, n_tgt = int(sys.argv[1]), int(sys.argv[2])
 trim = int(sys.argv[3]) if len(sys.argv) > 3 else 1

@@ -1,4 +1,6 @@
 import sys, numpy as np
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from open3d_slam_private_amd import capi, synth
 n_src, n_tgt = int(sys.argv[1]), int(sys.argv[2])
 sc = synth.make_scene(n_src, n_tgt, seed=1236)
