@@ -585,23 +585,30 @@ __device__ __forceinline__ float3 normalize3(float3 n) {
 // Reduce kSums (=32) doubles per lane over the 64 lanes of a wave with 32 shuffles instead of 192:
 // at every step a lane keeps one half of its values and hands the other half to its xor-partner.
 // On return lanes 2c and 2c+1 both hold the wave total of component c in v[0].
-__device__ __forceinline__ void wave_reduce32(double* v) {
-    const int lane = threadIdx.x & 63;
+template <int HALF, int BIT>
+__device__ __forceinline__ void wave_reduce_step(double (&v)[kSums], int lane) {
+    const bool up = (lane & BIT) != 0;
 #pragma unroll
-    for (int half = 16, bit = 32; half >= 1; half >>= 1, bit >>= 1) {
-        const bool up = (lane & bit) != 0;
-#pragma unroll
-        for (int k = 0; k < half; ++k) {
-            const double keep = up ? v[k + half] : v[k];
-            const double send = up ? v[k] : v[k + half];
-            v[k] = keep + __shfl_xor(send, bit);
-        }
+    for (int k = 0; k < HALF; ++k) {
+        const double keep = up ? v[k + HALF] : v[k];
+        const double send = up ? v[k] : v[k + HALF];
+        v[k] = keep + __shfl_xor(send, BIT);
     }
+}
+// (every index is a compile-time constant after unrolling: the array must stay in registers -- an earlier
+// version with a runtime `half` put it in scratch: 272 B/lane, 51 MB of scratch writes per launch)
+__device__ __forceinline__ void wave_reduce32(double (&v)[kSums]) {
+    const int lane = threadIdx.x & 63;
+    wave_reduce_step<16, 32>(v, lane);
+    wave_reduce_step<8, 16>(v, lane);
+    wave_reduce_step<4, 8>(v, lane);
+    wave_reduce_step<2, 4>(v, lane);
+    wave_reduce_step<1, 2>(v, lane);
     v[0] = v[0] + __shfl_xor(v[0], 1);
 }
 
 // block partial -> global: partials[blockIdx.x][kSums]  (256 threads = 4 waves)
-__device__ __forceinline__ void block_reduce_store(double* vals /* kSums per thread */, double* __restrict__ partials) {
+__device__ __forceinline__ void block_reduce_store(double (&vals)[kSums], double* __restrict__ partials) {
     __shared__ double sh[4][kSums];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     wave_reduce32(vals);
