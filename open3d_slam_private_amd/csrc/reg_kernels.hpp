@@ -405,6 +405,15 @@ __device__ __forceinline__ Best nearest_group(const Grid& g, float3 p, int sub, 
         const float r = g.rho[l];
         const float r2 = r * r;
         if (best.pos >= 0 && best.d2 <= r2) break;  // every point within rho was inside the box: exact
+        if (best.pos >= 0) {
+            // a candidate at distance sqrt(best.d2) exists, so the true neighbour is no farther: jump straight to
+            // the first radius that covers it (the levels in between could not terminate either)
+            while (l + 2 < g.n_levels) {
+                const float rn = g.rho[l + 1];
+                if (rn * rn >= best.d2) break;
+                ++l;
+            }
+        }
     }
     *level_out = min(l, g.n_levels - 1);
     return best;
