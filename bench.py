@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="extra measurement (config 5 analogue): S independent registrations in flight, one handle + "
+                         "HIP stream + host thread each; reported under \"batched\", never as `value`")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -162,6 +165,41 @@ def main():
     bytes_pp = KERNEL_BYTES_PER_POINT[dom]
     achieved = n_src * bytes_pp / (kern[dom]["avg_ms"] * 1e-3) / 1e9
 
+    # optional: S independent registrations concurrently (replicas only, no collective) -- SURVEY 8e / config 5
+    batched = None
+    if world == 1 and args.streams > 1:
+        import threading
+        regs = []
+        for _ in range(args.streams):
+            r = capi.Registration(p)
+            r.set_target_device(d_tgt.data_ptr(), 3, n_tgt, d_tnrm.data_ptr(), 3)
+            r.set_source_device(d_src.data_ptr(), 3, n_src, d_snrm.data_ptr(), 3)
+            r.register(T_init)
+            regs.append(r)
+        per = max(2, args.steps // 2)
+        go = threading.Barrier(args.streams + 1)
+
+        def work(r):
+            go.wait()
+            for _ in range(per):
+                r.register(T_init)          # ctypes releases the GIL: the host threads really run in parallel
+            go.wait()
+
+        ths = [threading.Thread(target=work, args=(r,)) for r in regs]
+        for t in ths:
+            t.start()
+        torch.cuda.synchronize()
+        go.wait()
+        tb0 = time.perf_counter()
+        go.wait()
+        tb = time.perf_counter() - tb0
+        for t in ths:
+            t.join()
+        batched = {"streams": args.streams, "registrations": args.streams * per,
+                   "iter_per_s": args.streams * per * ITERS / tb, "ms_per_registration_amortised": 1e3 * tb / (args.streams * per)}
+        for r in regs:
+            r.close()
+
     if rank == 0:
         value = world * ITERS * args.steps / elapsed
         line = {
@@ -184,6 +222,7 @@ def main():
                                    "achieved_GBs_end_to_end": n_src * ITER_BYTES_PER_POINT * ITERS * args.steps / elapsed / 1e9},
             "target_build_ms": float(reg.last_result.target_build_ms) if world == 1 else None,
             "band_stalls_last_step": int(reg.last_result.n_band_stalls) if world == 1 else None,
+            "batched": batched,
         }
         if not args.no_cpu_baseline:
             cores = os.cpu_count() or 1

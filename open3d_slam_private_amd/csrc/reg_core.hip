@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -1027,23 +1028,54 @@ __device__ __forceinline__ void block_pick1024(const uint32_t* h, int nb, uint32
 // predicted trimmed band + exact quantile inside it + the surviving band records; then (it->update) R8 + R9 on
 // the device -- 6x6 solve in fp64, x -> 4x4, T_iter <- dT * T_iter, transformation checkers -- and a mirror of
 // the outcome into mapped host memory followed by a sequence word the host polls.
+// Workgroup barrier that only waits for LDS traffic: global loads issued earlier stay in flight across it
+// (__syncthreads() drains vmcnt(0) first -- cdna_hip_programming.md, "Pipelining across barriers").
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
 __global__ void __launch_bounds__(1024)
 k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it, HostMirror* host,
                 unsigned long long seq, int fused, const float* __restrict__ band, float* __restrict__ w_out,
                 const SelectState* __restrict__ sel) {
     __shared__ double sh[32][kSums];
     __shared__ double tot[kSums];
-    __shared__ uint32_t hist[2048];
+    __shared__ uint32_t hist[2048 + 64];
     __shared__ uint32_t wave_tot[16];
     __shared__ uint32_t pick[2];
     __shared__ float s_limit;
     __shared__ uint32_t bd2[kBandCap];
+    __shared__ __attribute__((aligned(16))) uint32_t mir_w[(sizeof(HostMirror) + 3) / 4];
     __shared__ uint32_t small[64];
-    __shared__ uint32_t s_cnt;
-    if (it->done) return;
-    if (fused && it->stall) return;
+    __shared__ uint32_t s_cnt, s_csel, s_need_radix;
+    // read every state field this kernel branches on in ONE batch (each separate use would cost an L2 round trip)
+    const int s_done = it->done, s_stall = it->stall, s_use_trim = it->use_trim;
+    const float s_ratio = it->trim_ratio, s_band_lo = it->band_lo, s_band_hi = it->band_hi;
+    const uint32_t s_band_count = it->band_count;
+    if (s_done) return;
+    if (fused && s_stall) return;
     const unsigned long long st0 = __builtin_amdgcn_s_memtime();
     const int comp = threadIdx.x & (kSums - 1), part = threadIdx.x / kSums;  // 32 parts x 32 comps
+    // fused path: issue this thread's band-record loads right away (they only depend on the record count); the
+    // barriers below are LDS-only, so the loads stay in flight behind the partial sums
+    const bool trim = s_use_trim && s_ratio != 1.0f;
+    const uint32_t n_band = (fused && trim) ? min(s_band_count, (uint32_t)kBandCap) : 0u;
+    const bool add_comp = comp != 29 && comp != 31;
+    float pre[16];
+    uint32_t my_d2[kBandCap / 1024];
+    if (n_band) {
+#pragma unroll
+        for (int u = 0; u < kBandCap / 1024; ++u) {
+            const uint32_t i = threadIdx.x + 1024u * u;
+            my_d2[u] = i < n_band ? __float_as_uint(band[band_at(29, i)]) : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const uint32_t i = min((uint32_t)part + 32u * u, n_band - 1);
+            pre[u] = add_comp ? band[band_at(comp, i)] : 0.f;
+        }
+    }
     double t = 0;
     if (fused) {
         for (int b = part; b < kAccRows; b += 32) {
@@ -1057,28 +1089,26 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
     if (threadIdx.x == 0) {
         s_limit = INFINITY;
     }
-    __syncthreads();
+    lds_barrier();
     if (threadIdx.x < kSums) {
         double s = 0;
         for (int p = 0; p < 32; ++p) s += sh[p][threadIdx.x];
         tot[threadIdx.x] = s;
     }
-    __syncthreads();
-    const bool trim = it->use_trim && it->trim_ratio != 1.0f;
+    lds_barrier();
     const unsigned long long stA = __builtin_amdgcn_s_memtime();
-    unsigned long long stB = stA, stC = stA;
+    unsigned long long stB = stA, stC = stA, sx1 = stA, sx2 = stA, sx3 = stA;
     if (fused && trim) {
         // ---- verify the predicted band with exact counts, then select the exact quantile inside it
         const uint32_t n_finite = (uint32_t)llround(tot[29]), n_below = (uint32_t)llround(tot[31]);
-        const uint32_t n_band = it->band_count;
-        const uint32_t k = trim_rank(n_finite, it->trim_ratio);
-        const bool ok = n_finite == 0 || (n_band <= (uint32_t)kBandCap && n_below <= k && k < n_below + n_band);
+        const uint32_t k = trim_rank(n_finite, s_ratio);
+        const bool ok = n_finite == 0 || (s_band_count <= (uint32_t)kBandCap && n_below <= k && k < n_below + n_band);
         if (!ok) {
             if (threadIdx.x == 0) {
                 it->stall = 1;
                 it->band_count = 0;
                 host->stall = 1;
-                host->band_count = (int)n_band;
+                host->band_count = (int)s_band_count;
                 host->iterations = it->iterations;
                 host->done = 0;
                 __threadfence_system();
@@ -1087,51 +1117,82 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
             return;
         }
         if (n_finite != 0) {
-            // stage the band's d2 bit patterns in LDS once; issue this thread's share of the record loads NOW
-            // (they do not depend on the limit) so their latency hides behind the select
-            for (uint32_t i = threadIdx.x; i < n_band; i += 1024) bd2[i] = __float_as_uint(band[band_at(29, i)]);
-            float pre[16];
-            const bool add_comp = comp != 29 && comp != 31;
+            // stage the band's d2 bit patterns (loaded at kernel start) in LDS
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const uint32_t i = min((uint32_t)part + 32u * u, n_band - 1);
-                pre[u] = add_comp ? band[band_at(comp, i)] : 0.f;
+            for (int u = 0; u < kBandCap / 1024; ++u) {
+                const uint32_t i = threadIdx.x + 1024u * u;
+                if (i < n_band) bd2[i] = my_d2[u];
             }
             // One-level select: the band's values lie in [band_lo, band_hi), so the order-preserving key
             // (u - u_lo) * 2048 / (u_hi - u_lo) spreads them over 2048 bins (about one value per bin); the bin that
             // holds rank r is then resolved by direct ranking.  Crowded bin (> 64 equal-ish values): radix levels.
-            const uint32_t u_lo = __float_as_uint(it->band_lo), u_hi = __float_as_uint(it->band_hi);
-            const uint64_t span = (uint64_t)(u_hi > u_lo ? u_hi - u_lo : 1u);
+            const uint32_t u_lo = __float_as_uint(s_band_lo), u_hi = __float_as_uint(s_band_hi);
+            // order-preserving key without integer division: trunc(double(u - u_lo) * 2048 / span) (monotone in u)
+            const double kscale = 2048.0 / (double)(u_hi > u_lo ? u_hi - u_lo : 1u);
             uint32_t rank = k - n_below, prefix = 0;
-            for (int i = threadIdx.x; i < 2048; i += 1024) hist[i] = 0;
-            if (threadIdx.x == 0) s_cnt = 0;
-            __syncthreads();
-            for (uint32_t i = threadIdx.x; i < n_band; i += 1024) {
-                const uint32_t key = (uint32_t)(((uint64_t)(bd2[i] - u_lo) * 2048ull) / span);
-                atomicAdd(&hist[min(key, 2047u)], 1u);
+            sx1 = __builtin_amdgcn_s_memtime();
+            for (int i = threadIdx.x; i < 2048 + 64; i += 1024) hist[i] = 0;
+            if (threadIdx.x == 0) {
+                s_cnt = 0;
+                s_need_radix = 0;
             }
-            __syncthreads();
-            block_pick1024(hist, 2048, rank, wave_tot, pick);
-            const uint32_t bsel = pick[0], rsel = pick[1], csel = hist[pick[0]];
-            __syncthreads();
-            if (csel <= 64u) {
-                for (uint32_t i = threadIdx.x; i < n_band; i += 1024) {
-                    const uint32_t key = min((uint32_t)(((uint64_t)(bd2[i] - u_lo) * 2048ull) / span), 2047u);
-                    if (key == bsel) small[atomicAdd(&s_cnt, 1u)] = bd2[i];
+            lds_barrier();   // LDS-only barrier: the record loads issued above stay in flight
+            for (uint32_t i = threadIdx.x; i < n_band; i += 1024) {
+                const uint32_t key = (uint32_t)((double)(bd2[i] - u_lo) * kscale);
+                const uint32_t kk = min(key, 2047u);
+                atomicAdd(&hist[kk + (kk >> 5)], 1u);   // +1 pad per 32 bins: lane-contiguous reads below are conflict-free
+            }
+            lds_barrier();   // LDS-only barrier: the record loads issued above stay in flight
+            sx2 = __builtin_amdgcn_s_memtime();
+            if (threadIdx.x < 64) {
+                // wave 0 alone (wave-synchronous, no workgroup barriers): pick the bin, rank inside it
+                const int ln = threadIdx.x;
+                uint32_t loc = 0;
+                for (int j = 0; j < 32; ++j) loc += hist[33 * ln + j];
+                uint32_t incl = loc;
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t v = __shfl_up(incl, o);
+                    if (ln >= o) incl += v;
                 }
-                __syncthreads();
-                if (threadIdx.x < csel) {
-                    const uint32_t e = small[threadIdx.x];
-                    uint32_t r = 0;
-                    for (uint32_t j = 0; j < csel; ++j) {
-                        const uint32_t o = small[j];
-                        r += (o < e || (o == e && j < threadIdx.x)) ? 1u : 0u;
+                const uint32_t excl = incl - loc;
+                if (loc && rank >= excl && rank < incl) {
+                    uint32_t run = excl;
+                    for (int j = 0; j < 32; ++j) {
+                        const uint32_t hcount = hist[33 * ln + j];
+                        if (hcount && rank >= run && rank < run + hcount) {
+                            pick[0] = 32 * ln + j;
+                            pick[1] = rank - run;
+                            s_csel = hcount;
+                        }
+                        run += hcount;
                     }
-                    if (r == rsel) s_limit = __uint_as_float(e);
                 }
-                __syncthreads();
-                prefix = __float_as_uint(s_limit);
-            } else {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t bsel = pick[0], rsel = pick[1], csel = s_csel;
+                if (csel <= 64u) {
+                    for (uint32_t i = ln; i < n_band; i += 64) {
+                        const uint32_t key = min((uint32_t)((double)(bd2[i] - u_lo) * kscale), 2047u);
+                        if (key == bsel) small[atomicAdd(&s_cnt, 1u)] = bd2[i];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    if ((uint32_t)ln < csel) {
+                        const uint32_t e = small[ln];
+                        uint32_t rr = 0;
+                        for (uint32_t j = 0; j < csel; ++j) {
+                            const uint32_t o = small[j];
+                            rr += (o < e || (o == e && j < (uint32_t)ln)) ? 1u : 0u;
+                        }
+                        if (rr == rsel) s_limit = __uint_as_float(e);
+                    }
+                } else if (ln == 0) {
+                    s_need_radix = 1;
+                }
+            }
+            lds_barrier();   // LDS-only barrier: the record loads issued above stay in flight
+            sx3 = __builtin_amdgcn_s_memtime();
+            if (s_need_radix) {   // crowded bin (many equal distances): plain 3-level radix select, all threads
             for (int level = 0; level < 3; ++level) {
                 for (int i = threadIdx.x; i < 2048; i += 1024) hist[i] = 0;
                 __syncthreads();
@@ -1147,9 +1208,9 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
                 rank = pick[1];
                 __syncthreads();
             }
-            }
             if (threadIdx.x == 0) s_limit = __uint_as_float(prefix);
             __syncthreads();
+            }
             stB = __builtin_amdgcn_s_memtime();
             const float limit = s_limit;
             // ---- add the band records that survive the trim (component-wise, 32 parts)
@@ -1192,15 +1253,46 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
         if (threadIdx.x == 0) s_limit = sel->limit;
         __syncthreads();
     }
-    if (threadIdx.x < kSums) {
-        it->sums[threadIdx.x] = tot[threadIdx.x];
-        host->sums[threadIdx.x] = tot[threadIdx.x];
-    }
-    if (threadIdx.x != 0) return;
+    if (threadIdx.x < kSums) it->sums[threadIdx.x] = tot[threadIdx.x];
+    if (threadIdx.x >= 64) return;   // the rest is wave 0 only (wave-synchronous: no workgroup barriers below)
+    const int lane = threadIdx.x;
     const unsigned long long st1 = __builtin_amdgcn_s_memtime();
     unsigned long long st2 = st1, st3 = st1;
-    // band for the next iteration from the limits seen so far
-    {
+    const bool p2pl = it->cost == REG_COST_P2PL;
+    // ---- R8: 6x6 solve by Gauss-Jordan elimination on the augmented 6x7 system, one entry per lane (fp64).
+    // P2PL: A, b are first rounded to fp32 (the reference hands fp32 matrices to its fp64 solver).
+    const int r = lane >> 3, c = lane & 7;
+    double a = 0.0;
+    if (r < 6 && c < 7) {
+        if (c < 6) {
+            const int lo = r < c ? r : c, hi = r < c ? c : r;
+            const int k = lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo);   // index into the packed upper triangle
+            a = p2pl ? (double)(float)tot[k] : tot[k];
+        } else {
+            a = p2pl ? (double)(-(float)tot[21 + r]) : -tot[21 + r];
+        }
+    }
+    const double a_orig = a;
+    double dmax = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) dmax = fmax(dmax, fabs(__shfl(a_orig, j * 8 + j)));
+    bool well = dmax > 0.0;
+    const double piv_thr = (p2pl ? 1e-4 : 1e-10) * dmax;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const double pj = __shfl(a, j * 8 + j);
+        well = well && (pj > piv_thr);
+        const double ajc = __shfl(a, j * 8 + c);
+        const double arj = __shfl(a, r * 8 + j);
+        const double q = ajc / pj;
+        a = (r == j) ? q : a - arj * q;
+    }
+    double xs[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) xs[i] = __shfl(a, i * 8 + 6);
+    st2 = __builtin_amdgcn_s_memtime();
+    if (lane == 0) {
+        // band for the next iteration from the limits seen so far
         const float limit = s_limit;
         it->limit_prev = it->limit_last;
         it->limit_last = limit;
@@ -1214,96 +1306,117 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
             it->band_lo = limit * (1.0f - m);
             it->band_hi = limit * (1.0f + m);
         }
-        host->pad_nband = (int)it->band_count;
+        mir_w[100] = (uint32_t)it->band_count;
         it->band_count = 0;
         it->stall = 0;
-    }
-    if (it->update) {
-        if (tot[28] == 0.0) {
-            it->status = REG_NO_CORRESPONDENCES;
-            it->done = 1;
-        } else if (it->cost == REG_COST_P2PL) {
-            float H[36], b6[6], x[6], dT[16], Tn[16];
-            int k = 0;
-            for (int a = 0; a < 6; ++a)
-                for (int c = a; c < 6; ++c) {
-                    const float v = (float)tot[k++];
-                    H[6 * a + c] = v;
-                    H[6 * c + a] = v;
+        if (it->update) {
+            if (tot[28] == 0.0) {
+                it->status = REG_NO_CORRESPONDENCES;
+                it->done = 1;
+            } else if (p2pl) {
+                float x[6], dT[16], Tn[16];
+                int rank = 6;
+                if (well) {
+                    for (int i = 0; i < 6; ++i) x[i] = (float)xs[i];
+                } else {
+                    // ill-conditioned / rank deficient: eigen-solve with the fp32 rank threshold (minimum norm)
+                    float H[36], b6[6];
+                    int k = 0;
+                    for (int i = 0; i < 6; ++i)
+                        for (int j = i; j < 6; ++j) {
+                            const float v = (float)tot[k++];
+                            H[6 * i + j] = v;
+                            H[6 * j + i] = v;
+                        }
+                    for (int i = 0; i < 6; ++i) b6[i] = -(float)tot[21 + i];
+                    rank = solve6_p2pl(H, b6, x);
                 }
-            for (int a = 0; a < 6; ++a) b6[a] = -(float)tot[21 + a];
-            it->rank_last = solve6_p2pl_fast(H, b6, x);
-            st2 = __builtin_amdgcn_s_memtime();
-            x_to_T(x, dT);
-            m4_mul(dT, it->T, Tn);  // T_iter = real * T_iter (ICP.cpp:1213-1215)
-            for (int i = 0; i < 16; ++i) it->T[i] = Tn[i];
-            it->iterations += 1;
-            bool iterate;
-            if (it->fixed_iters > 0)
-                iterate = it->iterations < it->fixed_iters;
-            else
-                iterate = it->chk.check(Tn);
-            if (!iterate) it->done = 1;
-            st3 = __builtin_amdgcn_s_memtime();
-        } else {
-            double Hd[36], g[6], dl[6], E[16], Tn[16];
-            int k = 0;
-            for (int a = 0; a < 6; ++a)
-                for (int c = a; c < 6; ++c) Hd[6 * a + c] = Hd[6 * c + a] = tot[k++];
-            for (int a = 0; a < 6; ++a) g[a] = -tot[21 + a];
-            int rank = 6;
-            if (!solve_ldlt6(Hd, g, dl, 1e-10)) rank = solve_sym6(Hd, g, dl, 1e-12);
-            it->rank_last = rank;
-            se3_exp(dl, E);
-            for (int i = 0; i < 4; ++i)
-                for (int j = 0; j < 4; ++j) {
-                    double v = 0;
-                    for (int kk = 0; kk < 4; ++kk) v += it->Td[4 * i + kk] * E[4 * kk + j];
-                    Tn[4 * i + j] = v;
-                }
-            for (int i = 0; i < 16; ++i) {
-                it->Td[i] = Tn[i];
-                it->T[i] = (float)Tn[i];
-            }
-            it->iterations += 1;
-            if (it->fixed_iters > 0) {
-                if (it->iterations >= it->fixed_iters) it->done = 1;
+                it->rank_last = rank;
+                x_to_T(x, dT);
+                m4_mul(dT, it->T, Tn);  // T_iter = real * T_iter (ICP.cpp:1213-1215)
+                for (int i = 0; i < 16; ++i) it->T[i] = Tn[i];
+                it->iterations += 1;
+                bool iterate;
+                if (it->fixed_iters > 0)
+                    iterate = it->iterations < it->fixed_iters;
+                else
+                    iterate = it->chk.check(Tn);
+                if (!iterate) it->done = 1;
             } else {
-                const double dr = sqrt(dl[0] * dl[0] + dl[1] * dl[1] + dl[2] * dl[2]);
-                const double dt = sqrt(dl[3] * dl[3] + dl[4] * dl[4] + dl[5] * dl[5]);
-                if (dr < (double)it->gicp_rot_eps && dt < (double)it->gicp_trans_eps) {
-                    it->chk.converged = true;
-                    it->done = 1;
-                } else if (it->iterations >= it->max_iter) {
-                    it->chk.max_iter_reached = true;
-                    it->done = 1;
+                double dl[6], E[16], Tn[16];
+                int rank = 6;
+                if (well) {
+                    for (int i = 0; i < 6; ++i) dl[i] = xs[i];
+                } else {
+                    double Hd[36], g[6];
+                    int k = 0;
+                    for (int i = 0; i < 6; ++i)
+                        for (int j = i; j < 6; ++j) Hd[6 * i + j] = Hd[6 * j + i] = tot[k++];
+                    for (int i = 0; i < 6; ++i) g[i] = -tot[21 + i];
+                    rank = solve_sym6(Hd, g, dl, 1e-12);
+                }
+                it->rank_last = rank;
+                se3_exp(dl, E);
+                for (int i = 0; i < 4; ++i)
+                    for (int j = 0; j < 4; ++j) {
+                        double v = 0;
+                        for (int kk = 0; kk < 4; ++kk) v += it->Td[4 * i + kk] * E[4 * kk + j];
+                        Tn[4 * i + j] = v;
+                    }
+                for (int i = 0; i < 16; ++i) {
+                    it->Td[i] = Tn[i];
+                    it->T[i] = (float)Tn[i];
+                }
+                it->iterations += 1;
+                if (it->fixed_iters > 0) {
+                    if (it->iterations >= it->fixed_iters) it->done = 1;
+                } else {
+                    const double dr = sqrt(dl[0] * dl[0] + dl[1] * dl[1] + dl[2] * dl[2]);
+                    const double dt = sqrt(dl[3] * dl[3] + dl[4] * dl[4] + dl[5] * dl[5]);
+                    if (dr < (double)it->gicp_rot_eps && dt < (double)it->gicp_trans_eps) {
+                        it->chk.converged = true;
+                        it->done = 1;
+                    } else if (it->iterations >= it->max_iter) {
+                        it->chk.max_iter_reached = true;
+                        it->done = 1;
+                    }
                 }
             }
         }
+        st3 = __builtin_amdgcn_s_memtime();
+        // stage the host mirror in LDS (word layout of HostMirror); the whole wave then writes it out
+        HostMirror* m = reinterpret_cast<HostMirror*>(mir_w);
+        for (int i = 0; i < 16; ++i) m->T[i] = it->T[i];
+        m->iterations = it->iterations;
+        m->done = it->done;
+        m->status = it->status;
+        m->rank_last = it->rank_last;
+        m->converged = it->chk.converged ? 1 : 0;
+        m->max_iter_reached = it->chk.max_iter_reached ? 1 : 0;
+        m->stall = 0;
+        m->band_count = 0;
+        m->limit_last = it->limit_last;
+        m->limit_prev = it->limit_prev;
+        m->band_lo = it->band_lo;
+        m->band_hi = it->band_hi;
+        m->pad_nband = (int)mir_w[100];
+        m->stamps[0] = st1 - st0;
+        m->stamps[1] = st2 - st1;
+        m->stamps[2] = st3 - st2;
+        m->stamps[4] = stA - st0;
+        m->stamps[5] = stB - stA;
+        m->stamps[6] = stC - stB;
+        m->stamps[3] = sx1 - stA;
+        m->stamps[7] = ((sx2 - sx1) << 32) | (sx3 - sx2);
     }
-    for (int i = 0; i < 16; ++i) host->T[i] = it->T[i];
-    host->iterations = it->iterations;
-    host->done = it->done;
-    host->status = it->status;
-    host->rank_last = it->rank_last;
-    host->converged = it->chk.converged ? 1 : 0;
-    host->max_iter_reached = it->chk.max_iter_reached ? 1 : 0;
-    host->stall = 0;
-    host->band_count = 0;
-    host->limit_last = it->limit_last;
-    host->limit_prev = it->limit_prev;
-    host->band_lo = it->band_lo;
-    host->band_hi = it->band_hi;
-    host->stamps[0] = st1 - st0;
-    host->stamps[1] = st2 - st1;
-    host->stamps[2] = st3 - st2;
-    host->stamps[3] = __builtin_amdgcn_s_memtime() - st3;
-    host->stamps[4] = stA - st0;
-    host->stamps[5] = stB - stA;
-    host->stamps[6] = stC - stB;
-    host->stamps[7] = it->band_count;
+    if (lane < kSums) reinterpret_cast<HostMirror*>(mir_w)->sums[lane] = tot[lane];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // LDS writes of lane 0 visible to the wave
+    __builtin_amdgcn_wave_barrier();
+    constexpr int kMirrorWords = (int)(offsetof(HostMirror, seq) / 4);
+    uint32_t* hw = reinterpret_cast<uint32_t*>(host);
+    for (int w = lane; w < kMirrorWords; w += 64) hw[w] = mir_w[w];
     __threadfence_system();
-    __hip_atomic_store(&host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (lane == 0) __hip_atomic_store(&host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // results back into the caller's order: out[perm[i]] = value of slot i
@@ -2380,6 +2493,7 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
     if (getenv("O3D_STAMPS"))
         fprintf(stderr, "update kernel stamps (cycles): reduce %llu [rows %llu select %llu band-add %llu] solve %llu update+check %llu mirror %llu\n", mir->stamps[0],
                 mir->stamps[4], mir->stamps[5], mir->stamps[6], mir->stamps[1], mir->stamps[2], mir->stamps[3]);
+        fprintf(stderr, "   select detail: verify+stage-issue %llu, zero+hist+barriers %llu, wave0 pick/rank %llu\n", mir->stamps[3], mir->stamps[7] >> 32, mir->stamps[7] & 0xffffffffull);
     if (h->profiling) {
         for (size_t i = 0; i + 1 < h->prof_ev.size(); i += 2) {
             float ms = 0;
