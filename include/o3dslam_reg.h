@@ -181,6 +181,16 @@ REG_API reg_status reg_reduce_local(reg_handle* h, const float T_iter[16], float
 REG_API reg_status reg_solve_update(const reg_params* p, const double sums[32], const float T_iter[16],
                                     float T_next[16], int32_t* rank);
 
+/* Stream-ordered variant of the same exchange (no host round trip per iteration): each phase only ENQUEUES
+   kernels on the handle's stream; between phases the caller all-reduces -- on the SAME stream (RCCL) -- the device
+   buffers returned by reg_dist_buffers (hist: 3 x 2048 int32 counts, sums: 32 doubles).  Phases:
+   0 match + level-0 histogram | 1, 2 radix levels of the exact global trimmed quantile | 3 weights + normal
+   equations (local sums) | 4 solve + pose update + checkers on the device from the GLOBAL sums. */
+REG_API reg_status reg_dist_begin(reg_handle* h, const float T_start[16] /* NULL: identity (P2PL) / T_init (GICP) */);
+REG_API reg_status reg_dist_buffers(reg_handle* h, void** hist, void** sums);
+REG_API reg_status reg_dist_phase(reg_handle* h, int phase);
+REG_API reg_status reg_dist_finish(reg_handle* h, float T_out[16], reg_result* res);
+
 /* Host-side pieces of the path, exported so they can be checked without a GPU
    (PointToPlane.cpp:112-265 solve, :327-381 x -> 4x4; column-major 4x4). */
 REG_API int  reg_host_solve6(const float A[36], const float b[6], float x[6]);

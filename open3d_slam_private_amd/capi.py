@@ -54,7 +54,8 @@ class TargetInfo(C.Structure):
 EXPORTS = ["reg_default_params", "reg_shipped_params", "reg_create", "reg_destroy", "reg_last_error",
            "reg_set_stream", "reg_set_target", "reg_set_source", "reg_register", "reg_compute", "reg_prepare",
            "reg_linearize", "reg_get_correspondences", "reg_match_local", "reg_trim_histogram", "reg_reduce_local",
-           "reg_solve_update", "reg_host_solve6", "reg_host_x_to_T", "reg_host_centroid", "reg_get_target_info", "reg_profile_kernels", "reg_source_centroid_sums", "reg_prepare_centroid", "reg_compose"]
+           "reg_solve_update", "reg_host_solve6", "reg_host_x_to_T", "reg_host_centroid", "reg_get_target_info", "reg_profile_kernels", "reg_source_centroid_sums", "reg_prepare_centroid", "reg_compose",
+           "reg_dist_begin", "reg_dist_buffers", "reg_dist_phase", "reg_dist_finish"]
 
 
 def lib_path() -> str:
@@ -75,7 +76,10 @@ _lib = None
 
 
 def load_library():
-    """Load the HIP extension; fails loudly when it has not been built (no fallback exists)."""
+    """Load the HIP extension; fails loudly when it has not been built (no fallback exists).
+
+    Note: PyTorch-ROCm wheels bundle their own libamdhip64.so.7.  A process that uses BOTH torch (device buffers,
+    torch.distributed) and this library must `import torch` first, so that one HIP runtime serves both."""
     global _lib
     if _lib is not None:
         return _lib
@@ -109,6 +113,10 @@ def load_library():
     lib.reg_source_centroid_sums.argtypes = [vp, vp]
     lib.reg_prepare_centroid.argtypes = [vp, f32p, f32p]
     lib.reg_compose.argtypes = [vp, f32p, f32p]
+    lib.reg_dist_begin.argtypes = [vp, f32p]
+    lib.reg_dist_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    lib.reg_dist_phase.argtypes = [vp, C.c_int]
+    lib.reg_dist_finish.argtypes = [vp, f32p, C.POINTER(RegResult)]
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError if the library does not export what the header declares
     _lib = lib
@@ -272,6 +280,27 @@ class Registration:
         To = np.zeros(16, np.float32)
         self._check(self._lib.reg_compose(self._h, _ptr(_T_in(T_iter)), _ptr(To)))
         return _T_out(To)
+
+    # ---- stream-ordered distributed path ----------------------------------------------------------
+    def dist_begin(self, T_start=None):
+        self._check(self._lib.reg_dist_begin(self._h, _ptr(_T_in(T_start)) if T_start is not None else None))
+
+    def dist_buffers(self):
+        """(hist_ptr, sums_ptr): device addresses of the 3x2048 int32 histograms and the 32 float64 sums."""
+        hp, sp = C.c_void_p(), C.c_void_p()
+        self._check(self._lib.reg_dist_buffers(self._h, C.byref(hp), C.byref(sp)))
+        return hp.value, sp.value
+
+    def dist_phase(self, phase):
+        self._check(self._lib.reg_dist_phase(self._h, phase))
+
+    def dist_finish(self):
+        To = np.zeros(16, np.float32)
+        res = RegResult()
+        st = self._lib.reg_dist_finish(self._h, _ptr(To), C.byref(res))
+        self.last_result = res
+        self._check(st)
+        return _T_out(To), res
 
     def match_local(self, T_iter):
         self._check(self._lib.reg_match_local(self._h, _ptr(_T_in(T_iter))))

@@ -1419,6 +1419,27 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
     if (lane == 0) __hip_atomic_store(&host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Stream-ordered distributed path: this rank's workgroup partials -> 32 doubles (summed over ranks by the caller's
+// all-reduce before the update kernel runs).
+__global__ void __launch_bounds__(1024)
+k_partials_sum(const double* __restrict__ partials, int n_blocks, double* __restrict__ out, const IterState* __restrict__ it) {
+    __shared__ double sh[32][kSums];
+    if (it->done) {
+        if (threadIdx.x < kSums) out[threadIdx.x] = 0.0;   // a finished rank contributes nothing
+        return;
+    }
+    const int comp = threadIdx.x & (kSums - 1), part = threadIdx.x / kSums;
+    double t = 0;
+    for (int b = part; b < n_blocks; b += 32) t += partials[(size_t)b * kSums + comp];
+    sh[part][comp] = t;
+    __syncthreads();
+    if (threadIdx.x < kSums) {
+        double s = 0;
+        for (int p = 0; p < 32; ++p) s += sh[p][threadIdx.x];
+        out[threadIdx.x] = s;
+    }
+}
+
 // results back into the caller's order: out[perm[i]] = value of slot i
 __global__ void k_ids_from_pos(const int* __restrict__ pos, const float4* __restrict__ tgt, int64_t n,
                                const uint32_t* __restrict__ perm, int32_t* ids) {
@@ -1466,6 +1487,7 @@ struct reg_handle {
     std::string err;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    bool device_ok = false;   // false: reg_create could not get a HIP device (every entry point then fails loudly)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     // target
@@ -1497,6 +1519,7 @@ struct reg_handle {
     DevBuf i_hint, s_keys, s_keys2, s_perm, s_perm2, s_tmp, i_tmpf;
     const uint32_t* perm = nullptr;   // slot -> input index (null: identity)
     int last_stalls = 0;
+    unsigned long long dist_seq0 = 0;
     // loop profiling (params.profile_loop): HIP events around the search kernels of every iteration
     std::vector<hipEvent_t> prof_ev;   // pairs (start, stop)
     std::vector<int> prof_kind;        // 0: k_match, 1: k_iter_fused
@@ -1588,6 +1611,7 @@ reg_status reg_create(const reg_params* p, reg_handle** out) {
         return REG_DEVICE_ERROR;
     }
     h->own_stream = true;
+    h->device_ok = true;
     (void)hipEventCreate(&h->ev0);
     (void)hipEventCreate(&h->ev1);
     if (hipHostMalloc((void**)&h->h_mirror, sizeof(HostMirror), hipHostMallocMapped) != hipSuccess ||
@@ -1843,7 +1867,7 @@ extern "C" {
 reg_status reg_set_target(reg_handle* h, const float* xyz, int64_t xyz_stride, const float* nrm, int64_t nrm_stride,
                           const float* cov, int64_t m, int on_device) {
     if (!h) return REG_BAD_ARGUMENT;
-    if (!h->stream) return REG_DEVICE_ERROR;
+    if (!h->device_ok) return REG_DEVICE_ERROR;
     h->m = 0;
     h->have_match = false;
     if (m <= 0) {
@@ -1974,7 +1998,7 @@ reg_status reg_get_target_info(const reg_handle* h, reg_target_info* info) {
 reg_status reg_set_source(reg_handle* h, const float* xyz, int64_t xyz_stride, const float* nrm, int64_t nrm_stride,
                           const float* cov, int64_t n, int on_device) {
     if (!h) return REG_BAD_ARGUMENT;
-    if (!h->stream) return REG_DEVICE_ERROR;
+    if (!h->device_ok) return REG_DEVICE_ERROR;
     h->n = 0;
     h->prepared = false;
     h->have_match = false;
@@ -2034,7 +2058,7 @@ reg_status reg_set_source(reg_handle* h, const float* xyz, int64_t xyz_stride, c
 
 static reg_status check_ready(reg_handle* h, bool need_prepared) {
     if (!h) return REG_BAD_ARGUMENT;
-    if (!h->stream) return REG_DEVICE_ERROR;
+    if (!h->device_ok) return REG_DEVICE_ERROR;
     if (h->m == 0) {
         h->err = "no reference set (reg_set_target)";
         return REG_NOT_CONFIGURED;
@@ -2490,10 +2514,11 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
     HIPCHK(h, hipEventSynchronize(h->ev1));
     HIPCHK(h, hipGetLastError());
     (void)hipEventElapsedTime(&res->loop_ms, h->ev0, h->ev1);
-    if (getenv("O3D_STAMPS"))
+    if (getenv("O3D_STAMPS")) {
         fprintf(stderr, "update kernel stamps (cycles): reduce %llu [rows %llu select %llu band-add %llu] solve %llu update+check %llu mirror %llu\n", mir->stamps[0],
                 mir->stamps[4], mir->stamps[5], mir->stamps[6], mir->stamps[1], mir->stamps[2], mir->stamps[3]);
         fprintf(stderr, "   select detail: verify+stage-issue %llu, zero+hist+barriers %llu, wave0 pick/rank %llu\n", mir->stamps[3], mir->stamps[7] >> 32, mir->stamps[7] & 0xffffffffull);
+    }
     if (h->profiling) {
         for (size_t i = 0; i + 1 < h->prof_ev.size(); i += 2) {
             float ms = 0;
@@ -2676,6 +2701,126 @@ reg_status reg_solve_update(const reg_params* p, const double sums[32], const fl
         for (int i = 0; i < 16; ++i) Tr[i] = (float)Tn[i];
     }
     row_to_col(Tr, T_next);
+    return REG_OK;
+}
+
+// ---- stream-ordered distributed path --------------------------------------------------------------
+// The multi-GPU loop without a host round trip per iteration: every phase only ENQUEUES kernels on the handle's
+// stream; between the phases the caller all-reduces (RCCL, same stream) the buffers returned by reg_dist_buffers.
+//   phase 0: R3+R4 on this rank's slice, level-0 histogram of d2          -> all-reduce hist[0..2048)
+//   phase 1: pick level 0 from the GLOBAL histogram, build level 1        -> all-reduce hist[2048..4096)
+//   phase 2: pick level 1, build level 2                                  -> all-reduce hist[4096..6144)
+//   phase 3: weights (exact global trimmed limit) + normal equations      -> all-reduce sums[0..32)
+//   phase 4: R8+R9 on the device from the global sums (identical on every rank)
+// Without TrimmedDist (or GICP) phases 1 and 2 are no-ops and no histogram needs reducing.
+reg_status reg_dist_begin(reg_handle* h, const float T_start[16]) {
+    reg_status s = check_ready(h, true);
+    if (s != REG_OK) return s;
+    float Tr[16];
+    if (T_start) {
+        col_to_row(T_start, Tr);
+    } else if (h->prm.cost == REG_COST_P2PL) {
+        m4_identity(Tr);
+    } else {
+        std::memcpy(Tr, h->T_init, 64);
+    }
+    HIPCHK(h, hipSetDevice(h->prm.device));
+    s = init_iter_state(h, Tr, 1);
+    if (s != REG_OK) return s;
+    HIPCHK(h, hipMemsetAsync(h->i_hist.p, 0, 3 * 2048 * 4, h->stream));
+    h->dist_seq0 = h->seq;
+    return REG_OK;
+}
+
+reg_status reg_dist_buffers(reg_handle* h, void** hist, void** sums) {
+    if (!h || !hist || !sums) return REG_BAD_ARGUMENT;
+    if (h->n == 0) return REG_NOT_CONFIGURED;
+    *hist = h->i_hist.p;
+    *sums = h->i_sums.p;
+    return REG_OK;
+}
+
+reg_status reg_dist_phase(reg_handle* h, int phase) {
+    reg_status s = check_ready(h, true);
+    if (s != REG_OK) return s;
+    const bool trim = h->prm.cost == REG_COST_P2PL && h->prm.use_trimmed;
+    uint32_t* hist0 = h->i_hist.as<uint32_t>();
+    SelectState* st = h->i_state.as<SelectState>();
+    const IterState* it = h->i_iter.as<IterState>();
+    const int hb = std::min(h->n_blocks, 128);
+    switch (phase) {
+        case 0:
+            s = enqueue_match(h);
+            if (s != REG_OK) return s;
+            if (trim) k_hist_level0<<<hb, 256, 0, h->stream>>>(h->i_d2.as<float>(), h->n, h->shift0, hist0, it);
+            break;
+        case 1:
+            if (trim)
+                k_select_level<<<hb, 256, 0, h->stream>>>(h->i_d2.as<float>(), h->n, 1, h->shift0, h->prm.trim_ratio,
+                                                          hist0, hist0 + 2048, nullptr, st, it);
+            break;
+        case 2:
+            if (trim)
+                k_select_level<<<hb, 256, 0, h->stream>>>(h->i_d2.as<float>(), h->n, 2, h->shift0, h->prm.trim_ratio,
+                                                          hist0 + 2048, hist0 + 4096, hist0, st, it);
+            break;
+        case 3: {
+            if (h->prm.cost == REG_COST_P2PL) {
+                const FilterCfg f = make_filter_cfg(h, h->prm.use_trimmed ? 2 : 0);
+                k_linearize_p2pl<<<h->n_blocks, 256, 0, h->stream>>>(
+                    h->s_xyz.as<float4>(), h->has_snrm ? h->s_nrm.as<float4>() : nullptr, h->n, it, h->i_pos.as<int>(),
+                    h->i_d2.as<float>(), h->t_pts.as<float4>(), h->t_nrm.as<float4>(), f, st, hist0 + 4096, hist0 + 2048,
+                    h->shift0, nullptr, h->i_partials.as<double>());
+            } else {
+                k_linearize_gicp<<<h->n_blocks, 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->s_cov.as<float4>(), h->n, it,
+                                                                     h->i_pos.as<int>(), h->i_d2.as<float>(),
+                                                                     h->t_pts.as<float4>(), h->t_cov.as<float4>(), nullptr,
+                                                                     h->i_partials.as<double>());
+            }
+            k_partials_sum<<<1, 1024, 0, h->stream>>>(h->i_partials.as<double>(), h->n_blocks, h->i_sums.as<double>(), it);
+            break;
+        }
+        case 4:
+            ++h->seq;
+            k_reduce_update<<<1, 1024, 0, h->stream>>>(h->i_sums.as<double>(), 1, h->i_iter.as<IterState>(), h->d_mirror,
+                                                       h->seq, 0, nullptr, nullptr,
+                                                       h->prm.cost == REG_COST_P2PL ? st : nullptr);
+            break;
+        default:
+            return REG_BAD_ARGUMENT;
+    }
+    return REG_OK;
+}
+
+// Waits for everything enqueued on the stream, then reports like reg_register (T_out composed with R10).
+reg_status reg_dist_finish(reg_handle* h, float T_out[16], reg_result* res) {
+    reg_status s = check_ready(h, true);
+    if (s != REG_OK) return s;
+    if (!T_out) return REG_BAD_ARGUMENT;
+    reg_result local;
+    if (!res) res = &local;
+    std::memset(res, 0, sizeof(*res));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    const HostMirror* mir = h->h_mirror;
+    if (mirror_seq(h) <= h->dist_seq0) {
+        h->err = "reg_dist_finish: no iteration has completed since reg_dist_begin";
+        return REG_NOT_CONFIGURED;
+    }
+    res->iterations = mir->iterations;
+    res->converged = mir->converged;
+    res->max_iter_reached = mir->max_iter_reached;
+    res->rank_last = mir->rank_last;
+    fill_result(h, mir->sums, res);
+    if (mir->status != REG_OK) {
+        h->err = "ErrorMinimizer: no point to minimize";
+        return (reg_status)mir->status;
+    }
+    float T_iter[16], Tout_row[16];
+    std::memcpy(T_iter, mir->T, 64);
+    compose_rowmajor(h, T_iter, Tout_row);
+    row_to_col(T_iter, res->T_iter_last);
+    row_to_col(Tout_row, T_out);
     return REG_OK;
 }
 

@@ -95,3 +95,47 @@ class DistributedRegistration:
         for _ in range(self.fixed_iters):
             T, sums = self.iterate(T)
         return T, sums
+
+
+class _DevArray:
+    """Minimal __cuda_array_interface__ holder: lets torch alias device memory owned by the C library."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+class StreamDistributedRegistration:
+    """Same exchange as DistributedRegistration, but stream-ordered: per Gauss-Newton iteration the host only
+    enqueues 5 kernel phases and (TrimmedDist) 3 + 1 all-reduces on ONE HIP stream -- no host synchronisation
+    until the end.  `reg` is a capi.Registration whose stream is torch's current stream on `device`;
+    `all_reduce(tensor)` defaults to torch.distributed.all_reduce (RCCL)."""
+
+    def __init__(self, reg, use_trimmed, iters, dist=None, device=None, all_reduce=None):
+        import torch
+        self.reg, self.use_trimmed, self.iters, self.dist = reg, use_trimmed, iters, dist
+        hist_ptr, sums_ptr = reg.dist_buffers()
+        dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.hist = torch.as_tensor(_DevArray(hist_ptr, (3, 2048), "<i4"), device=dev)
+        self.sums = torch.as_tensor(_DevArray(sums_ptr, (32,), "<f8"), device=dev)
+        if all_reduce is not None:
+            self._ar = all_reduce
+        elif dist is not None and dist.get_world_size() > 1:
+            self._ar = lambda t: dist.all_reduce(t)
+        else:
+            self._ar = lambda t: None
+
+    def run(self, T_start=None):
+        reg = self.reg
+        reg.dist_begin(T_start)
+        for _ in range(self.iters):
+            reg.dist_phase(0)
+            if self.use_trimmed:
+                self._ar(self.hist[0])
+                reg.dist_phase(1)
+                self._ar(self.hist[1])
+                reg.dist_phase(2)
+                self._ar(self.hist[2])
+            reg.dist_phase(3)
+            self._ar(self.sums)
+            reg.dist_phase(4)
+        return reg.dist_finish()

@@ -2,6 +2,7 @@ import os
 import sys
 
 import pytest
+import torch  # noqa: F401  -- must be imported BEFORE the HIP library: torch bundles its own libamdhip64 (same soname)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
