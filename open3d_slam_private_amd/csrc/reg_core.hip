@@ -46,6 +46,7 @@ struct IterState {
     float limit_prev;         // ... and of the one before
     unsigned int band_count;  // records appended to the band buffer in this iteration
     unsigned int band_cap;
+    int debug_narrow_band;
 };
 
 // What the update kernel mirrors into mapped host memory (the host polls `seq`).
@@ -1303,6 +1304,7 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
             const float prev = it->limit_prev;
             float m = 0.3f;
             if (prev < INFINITY && prev > 0.f) m = fminf(fmaxf(2.0f * fabsf(limit - prev) / limit + 0.01f, 0.01f), 0.6f);
+            if (it->debug_narrow_band) m = 1e-7f;   // test hook: forces band mispredictions (stall + repair path)
             it->band_lo = limit * (1.0f - m);
             it->band_hi = limit * (1.0f + m);
         }
@@ -2178,6 +2180,7 @@ static reg_status init_iter_state(reg_handle* h, const float* T_row, int update)
     st->use_trim = (h->prm.cost == REG_COST_P2PL && h->prm.use_trimmed) ? 1 : 0;
     st->trim_ratio = h->prm.trim_ratio;
     st->band_cap = kBandCap;
+    st->debug_narrow_band = (h->prm.debug_flags & 8) ? 1 : 0;
     HIPCHK(h, hipMemcpyAsync(h->i_iter.p, st, sizeof(IterState), hipMemcpyHostToDevice, h->stream));
     return REG_OK;
 }

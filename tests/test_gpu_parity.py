@@ -395,3 +395,75 @@ def test_stream_ordered_distributed_path_two_slices_one_gpu():
         assert dt <= 1e-6 and dr <= 1e-6, (dt, dr)
         assert res.iterations == 8 and res.n_inliers == res_ref.n_inliers
     assert np.array_equal(outs[0][0], outs[1][0])      # every rank holds the identical pose
+
+
+def _register(sc, **over):
+    p = capi.shipped_params()
+    for k, v in over.items():
+        setattr(p, k, v)
+    reg = capi.Registration(p)
+    reg.set_target(sc.tgt_xyz, sc.tgt_nrm)
+    reg.set_source(sc.src_xyz, sc.src_nrm)
+    T, res = reg.register(np.eye(4))
+    ids, d2, w = reg.correspondences()
+    return T, res, ids, d2, w
+
+
+@pytest.mark.parametrize("seed", [101, 102, 103])
+def test_fused_and_generic_iterations_give_the_same_registration(seed):
+    """The 2-launch fused iteration (predicted trim band, resolved exactly) must reproduce the generic
+    select-based iteration: same iteration count, same final pose, same last-iteration weights."""
+    sc = synth.make_scene(15000, 150000, seed=seed)
+    Tg, rg, idg, d2g, wg = _register(sc, fixed_iters=12, disable_fused=1)
+    Tf, rf, idf, d2f, wf = _register(sc, fixed_iters=12)
+    assert rf.n_band_stalls == 0
+    dt, dr = synth.pose_error(Tf, Tg)
+    assert dt <= 1e-6 and dr <= 1e-6, (dt, dr)
+    assert rf.n_inliers == rg.n_inliers and rf.n_matched == rg.n_matched
+    assert np.array_equal(idf, idg) and np.array_equal(d2f.view(np.uint32), d2g.view(np.uint32))
+    assert np.array_equal(wf, wg)
+    assert abs(rf.error - rg.error) <= 1e-9 * rg.error
+
+
+def test_band_misprediction_stalls_and_is_repaired_exactly():
+    """debug_flags & 8 shrinks the predicted band to nothing, so every fused iteration fails its verification:
+    the device must stall, the host must re-run the iteration on the generic path, and the result must not change."""
+    sc = synth.make_scene(15000, 150000, seed=104)
+    Tg, rg, *_ = _register(sc, fixed_iters=14, disable_fused=1)
+    Ts, rs, *_ = _register(sc, fixed_iters=14, debug_flags=8)
+    assert rs.n_band_stalls >= 1
+    assert rs.iterations == 14
+    dt, dr = synth.pose_error(Ts, Tg)
+    assert dt <= 1e-6 and dr <= 1e-6, (dt, dr)
+    assert rs.n_inliers == rg.n_inliers
+    # and with the checkers instead of a fixed count
+    Tc, rc, *_ = _register(sc, debug_flags=8)
+    To, ro = orc.icp_p2pl(sc.tgt_xyz, sc.tgt_nrm, sc.src_xyz, sc.src_nrm, max_dist=0.5, trim_ratio=0.9,
+                          max_normal_angle=1.57, max_iter=30, min_diff_rot=0.001, min_diff_trans=0.008, smooth_len=3)
+    assert rc.iterations == ro.iterations
+    dt, dr = synth.pose_error(Tc, To)
+    assert dt <= 1e-4 and dr <= 1e-4
+
+
+def test_unbounded_max_dist_and_no_filters():
+    """maxDist = inf (the reference's default matcher) with an empty outlier chain: every point is matched
+    (the search falls through to a full scan when needed) and weights are all one (OutlierFilter.cpp:70-84)."""
+    sc = synth.make_scene(3000, 20000, seed=105)
+    p = capi.default_params()
+    p.use_trimmed = 0
+    reg = capi.Registration(p)
+    reg.set_target(sc.tgt_xyz, sc.tgt_nrm)
+    far = sc.src_xyz.copy()
+    far[:50] += np.float32(30.0)            # some points far outside the map
+    reg.set_source(far)
+    reg.prepare(np.eye(4))
+    H, b, err, cnt = reg.linearize(np.eye(4))
+    ids, d2, w = reg.correspondences()
+    c_ref, c_read = orc.centroid(sc.tgt_xyz), orc.centroid(far)
+    tree = orc.KdTree(sc.tgt_xyz - c_ref)
+    A = np.eye(4, dtype=np.float32); A[:3, 3] = -c_ref
+    B = np.eye(4, dtype=np.float32); B[:3, 3] = c_read
+    rd = _xf(_m4(_m4(A, np.eye(4, dtype=np.float32)), B), far - c_read)
+    oid, od2 = tree.knn(rd, np.eye(4), max_dist=math.inf)
+    assert (ids >= 0).all() and cnt == far.shape[0] and (w == 1).all()
+    assert np.array_equal(ids, oid) and np.array_equal(d2.view(np.uint32), od2.view(np.uint32))
