@@ -209,6 +209,20 @@ def main():
         for r in regs:
             r.close()
 
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the number comes from
+    # the committed rocprofv3 --pmc passes of THIS command (tools/collect_profiles.sh -> profiles/r01_pmc_traffic.json;
+    # FETCH_SIZE doubled as the gfx950 guide prescribes and as the k_stream calibration in that file confirms).
+    traffic, traffic_src = None, None
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        if args.workload == "c2" and world == 1:
+            for kname, kv in pj["kernels"].items():
+                if kname.startswith(dom):
+                    traffic = kv["hbm_bytes_per_launch_corrected"]
+                    traffic_src = "profiles/r01_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, bytes per launch)"
+    except (OSError, KeyError, ValueError):
+        pass
+
     if rank == 0:
         value = world * ITERS * args.steps / elapsed
         line = {
@@ -223,7 +237,8 @@ def main():
                        "parallelism": f"point-partitioned x{world}" if world > 1 else "single GPU",
                        "cell_size_m": info.cell_size, "n_bricks": info.n_bricks},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": n_src * bytes_pp,
                          "kernel_ms": kern[dom]["avg_ms"], "launches": kern[dom]["launches"],
                          "bytes_per_point": bytes_pp},
             "kernels": kern,

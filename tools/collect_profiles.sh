@@ -1,0 +1,14 @@
+#!/bin/bash
+# Collects the round's profile artefacts on the GPU box (run through gpurun from the repo root):
+#   kernel trace + stats of the default bench command, FETCH_SIZE / WRITE_SIZE PMC passes (separate runs, as the
+#   MI355X guide prescribes), and the FETCH_SIZE calibration on known byte counts.
+set -o pipefail
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/profiles_r01
+rm -rf $OUT && mkdir -p $OUT
+CMD="python bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/bench_trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $CMD > $OUT/bench_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $CMD > $OUT/bench_write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/calib_fetch -- ./tools/tools_calib > $OUT/calib.log 2>&1
+python tools/summarise_profiles.py $OUT

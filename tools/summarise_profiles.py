@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 CSVs collected by tools/collect_profiles.sh into the small tracked files under profiles/."""
+import collections, csv, glob, json, os, shutil, sys
+
+out = sys.argv[1]
+dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+os.makedirs(dst, exist_ok=True)
+
+
+def counters(d):
+    fs = glob.glob(os.path.join(out, d, "*", "*counter_collection.csv"))
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    if fs:
+        for r in csv.DictReader(open(fs[0])):
+            agg[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return agg
+
+
+stats = glob.glob(os.path.join(out, "trace", "*", "*kernel_stats.csv"))
+if stats:
+    shutil.copy(stats[0], os.path.join(dst, "r01_bench_c2_kernel_stats.csv"))
+trace = glob.glob(os.path.join(out, "trace", "*", "*kernel_trace.csv"))
+dur = collections.defaultdict(list)
+if trace:
+    for r in csv.DictReader(open(trace[0])):
+        dur[r["Kernel_Name"].split("(")[0].replace("void ", "")].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+fetch, write, calib = counters("pmc_fetch"), counters("pmc_write"), counters("calib_fetch")
+# calibration: FETCH_SIZE is reported in KiB
+cal = {}
+for k, known in (("k_stream", float(1 << 30)), ("k_gather16", float((1 << 30) // 4))):
+    v = calib.get(k, {}).get("FETCH_SIZE")
+    if v:
+        cal[k] = {"known_useful_bytes": known, "FETCH_SIZE_KiB_mean": sum(v) / len(v),
+                  "reported_over_known": (sum(v) / len(v)) * 1024.0 / known}
+summary = {"command": "python bench.py --steps 10 --warmup 2 --no-cpu-baseline", "calibration": cal, "kernels": {}}
+stream_ratio = cal.get("k_stream", {}).get("reported_over_known", 0.5)
+for k in sorted(set(fetch) | set(write)):
+    if not any(x in k for x in ("k_match", "k_iter_fused", "k_linearize", "k_reduce_update", "k_select", "k_hist")):
+        continue
+    f = fetch.get(k, {}).get("FETCH_SIZE", [])
+    w = write.get(k, {}).get("WRITE_SIZE", [])
+    d = dur.get(k, [])
+    summary["kernels"][k] = {
+        "launches": len(f),
+        "avg_us": sum(d) / len(d) if d else None,
+        "FETCH_SIZE_KiB_mean": sum(f) / len(f) if f else None,
+        "WRITE_SIZE_KiB_mean": sum(w) / len(w) if w else None,
+        # gfx950: FETCH_SIZE counts 128-byte requests as 64 B for wide (16 B/lane) reads -> divide by the measured ratio
+        "hbm_bytes_per_launch_corrected": ((sum(f) / len(f)) * 1024.0 / stream_ratio if f else 0.0) + ((sum(w) / len(w)) * 1024.0 if w else 0.0),
+    }
+json.dump(summary, open(os.path.join(dst, "r01_pmc_traffic.json"), "w"), indent=1)
+with open(os.path.join(dst, "r01_bench_c2_trace_summary.txt"), "w") as fh:
+    for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
+        v2 = sorted(v)
+        fh.write(f"{k[:60]:62s} n={len(v):5d} tot={sum(v)/1000:9.3f}ms avg={sum(v)/len(v):9.2f}us med={v2[len(v)//2]:9.2f} min={v2[0]:8.2f} max={v2[-1]:9.2f}\n")
+for line in open(os.path.join(out, "bench_trace.log")):
+    if line.startswith('{"metric"'):
+        open(os.path.join(dst, "r01_bench_c2_line.json"), "w").write(line)
+print(json.dumps(summary, indent=1))
