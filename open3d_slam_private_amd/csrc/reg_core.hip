@@ -69,6 +69,10 @@ __device__ __forceinline__ int xcd_block(int n_blocks) {
     return (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
 }
 
+struct Xf4 {
+    float m[16];
+};
+
 __device__ __forceinline__ Xf load_xf(const IterState* it) {
     Xf x;
 #pragma unroll
@@ -247,6 +251,40 @@ __global__ void k_halo_insert(const float4* __restrict__ pts_sorted, int64_t n, 
 // kernels: reading preparation (R2)
 // =================================================================================================
 
+// Reading-preparation state computed on the device (no host round trip between the centroid reduction and the
+// kernels that need it): centroid of the reading and T0 = T_refIn_refMean^-1 * T_init * T_readIn_readMean.
+struct PrepState {
+    float c_read[3];
+    float pad;
+    float T0[16];   // row-major
+};
+// sums: integer centroid sums (NC1); c_override != null: use the given (global, multi-GPU) centroid instead.
+__global__ void k_make_T0(const unsigned long long* __restrict__ sums, int64_t n, float3 c_ref, Xf4 T_init, int centre,
+                          int use_override, float3 c_override, PrepState* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float c[3] = {0.f, 0.f, 0.f};
+    if (centre) {
+        if (use_override) {
+            c[0] = c_override.x; c[1] = c_override.y; c[2] = c_override.z;
+        } else {
+            for (int k = 0; k < 3; ++k) c[k] = (float)((double)(long long)sums[k] / (65536.0 * (double)n));
+        }
+    }
+    float A[16], B[16], tmp[16], T0[16];
+    m4_identity(A);
+    m4_identity(B);
+    if (centre) {
+        A[3] = -c_ref.x; A[7] = -c_ref.y; A[11] = -c_ref.z;   // T_refIn_refMean^-1
+        B[3] = c[0]; B[7] = c[1]; B[11] = c[2];               // T_readIn_readMean
+        m4_mul(A, T_init.m, tmp);
+        m4_mul(tmp, B, T0);
+    } else {
+        for (int i = 0; i < 16; ++i) T0[i] = T_init.m[i];
+    }
+    for (int k = 0; k < 3; ++k) out->c_read[k] = c[k];
+    for (int i = 0; i < 16; ++i) out->T0[i] = T0[i];
+}
+
 // Morton key of the bin the (pre-transformed) reading point falls into: neighbouring lanes then search
 // neighbouring bins (speed only -- results are reported in the caller's order).
 __device__ __forceinline__ uint32_t spread10(uint32_t v) {
@@ -257,17 +295,21 @@ __device__ __forceinline__ uint32_t spread10(uint32_t v) {
     v = (v | (v << 2)) & 0x09249249u;
     return v;
 }
-__global__ void k_source_keys(const float* __restrict__ xyz, int64_t stride, int64_t n, float cx, float cy, float cz,
-                              Xf T0, int centre, float ox, float oy, float oz, float inv_c, float dimx, float dimy,
-                              float dimz, int shift, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+__global__ void k_source_keys(const float* __restrict__ xyz, int64_t stride, int64_t n,
+                              const PrepState* __restrict__ ps, int centre, float ox, float oy, float oz, float inv_c,
+                              float dimx, float dimy, float dimz, int shift, uint32_t* __restrict__ keys,
+                              uint32_t* __restrict__ vals) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
+    Xf T0;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) T0.m[k] = ps->T0[k];
     const float* p = xyz + i * stride;
     float x = p[0], y = p[1], z = p[2];
     if (centre) {
-        x = x - cx;
-        y = y - cy;
-        z = z - cz;
+        x = x - ps->c_read[0];
+        y = y - ps->c_read[1];
+        z = z - ps->c_read[2];
     }
     const float3 q = xf_point(T0, x, y, z);
     const uint32_t bx = (uint32_t)fminf(fmaxf(bin_coord_f(q.x, ox, inv_c), 0.f), dimx - 1.f) >> shift;
@@ -278,12 +320,24 @@ __global__ void k_source_keys(const float* __restrict__ xyz, int64_t stride, int
 }
 
 // reading' = T0 * (p - c_read), normals' = R0 * n  (ICP.cpp:966-984); slot i holds input point perm[i]
+// Also clears the per-registration scratch (level hints, trimmed-quantile histograms, accumulator replicas), so the
+// registration needs no memset launches.
 __global__ void k_prepare_source(const float* __restrict__ xyz, int64_t stride, const float* __restrict__ nrm,
-                                 int64_t nrm_stride, int64_t n, float cx, float cy, float cz, Xf T0, int centre,
+                                 int64_t nrm_stride, int64_t n, const PrepState* __restrict__ ps, int centre,
                                  const uint32_t* __restrict__ perm, float4* __restrict__ out_xyz,
-                                 float4* __restrict__ out_nrm) {
+                                 float4* __restrict__ out_nrm, uint8_t* __restrict__ hint, uint32_t* __restrict__ hist,
+                                 double* __restrict__ acc, int n_acc) {
+    if (blockIdx.x == 0) {
+        for (int k = threadIdx.x; k < 3 * 2048; k += blockDim.x) hist[k] = 0u;
+        for (int k = threadIdx.x; k < n_acc; k += blockDim.x) acc[k] = 0.0;
+    }
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
+    hint[i] = 0;
+    Xf T0;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) T0.m[k] = ps->T0[k];
+    const float cx = ps->c_read[0], cy = ps->c_read[1], cz = ps->c_read[2];
     const int64_t src = perm ? (int64_t)perm[i] : i;
     const float* p = xyz + src * stride;
     float x = p[0], y = p[1], z = p[2];
@@ -1303,7 +1357,7 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
         } else {
             const float prev = it->limit_prev;
             float m = 0.3f;
-            if (prev < INFINITY && prev > 0.f) m = fminf(fmaxf(2.0f * fabsf(limit - prev) / limit + 0.01f, 0.01f), 0.6f);
+            if (prev < INFINITY && prev > 0.f) m = fminf(fmaxf(2.0f * fabsf(limit - prev) / limit + 0.003f, 0.003f), 0.6f);
             if (it->debug_narrow_band) m = 1e-7f;   // test hook: forces band mispredictions (stall + repair path)
             it->band_lo = limit * (1.0f - m);
             it->band_hi = limit * (1.0f + m);
@@ -1490,7 +1544,8 @@ struct reg_handle {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool device_ok = false;   // false: reg_create could not get a HIP device (every entry point then fails loudly)
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_iter = nullptr;
+    bool iter_copy_pending = false;
 
     // target
     int64_t m = 0;
@@ -1518,6 +1573,9 @@ struct reg_handle {
     DevBuf i_iter;                    // IterState on the device
     unsigned long long seq = 0;
     DevBuf t_halo_start, t_halo_cursor, t_halo_pts, i_band, i_acc;
+    DevBuf s_prep;
+    PrepState* h_prep = nullptr;      // pinned host copy of the device-side preparation state
+    bool prep_pending = false;        // h_prep not yet folded into c_read / T0
     DevBuf i_hint, s_keys, s_keys2, s_perm, s_perm2, s_tmp, i_tmpf;
     const uint32_t* perm = nullptr;   // slot -> input index (null: identity)
     int last_stalls = 0;
@@ -1542,12 +1600,6 @@ struct reg_handle {
 
 static inline void col_to_row(const float* c, float* r) { m4_transpose(c, r); }
 static inline void row_to_col(const float* r, float* c) { m4_transpose(r, c); }
-
-static Xf make_xf(const float* T_row) {
-    Xf x;
-    std::memcpy(x.m, T_row, 12 * sizeof(float));
-    return x;
-}
 
 static inline int grid_for(int64_t n, int block = 256) { return (int)((n + block - 1) / block); }
 
@@ -1616,9 +1668,11 @@ reg_status reg_create(const reg_params* p, reg_handle** out) {
     h->device_ok = true;
     (void)hipEventCreate(&h->ev0);
     (void)hipEventCreate(&h->ev1);
+    (void)hipEventCreateWithFlags(&h->ev_iter, hipEventDisableTiming);
     if (hipHostMalloc((void**)&h->h_mirror, sizeof(HostMirror), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&h->d_mirror, h->h_mirror, 0) != hipSuccess ||
         hipHostMalloc((void**)&h->h_iter, sizeof(IterState), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&h->h_prep, sizeof(PrepState), hipHostMallocDefault) != hipSuccess ||
         h->i_iter.reserve(sizeof(IterState)) != hipSuccess) {
         h->err = "hipHostMalloc / hipMalloc of the iteration state failed";
         *out = h;
@@ -1635,12 +1689,14 @@ void reg_destroy(reg_handle* h) {
                       &h->t_vals2, &h->t_pts, &h->t_nrm, &h->t_cov, &h->t_flags, &h->t_scan, &h->t_hash, &h->t_cells,
                       &h->t_tmp, &h->t_misc, &h->s_raw, &h->s_nrm_raw, &h->s_cov_raw, &h->s_xyz, &h->s_nrm, &h->s_cov,
                       &h->s_misc, &h->i_pos, &h->i_d2, &h->i_w, &h->i_hist, &h->i_state, &h->i_partials, &h->i_sums,
-                      &h->i_ids, &h->i_iter, &h->t_halo_start, &h->t_halo_cursor, &h->t_halo_pts, &h->i_band, &h->i_acc, &h->i_hint, &h->s_keys, &h->s_keys2, &h->s_perm, &h->s_perm2, &h->s_tmp, &h->i_tmpf};
+                      &h->i_ids, &h->s_prep, &h->i_iter, &h->t_halo_start, &h->t_halo_cursor, &h->t_halo_pts, &h->i_band, &h->i_acc, &h->i_hint, &h->s_keys, &h->s_keys2, &h->s_perm, &h->s_perm2, &h->s_tmp, &h->i_tmpf};
     for (DevBuf* b : bufs) b->release();
     if (h->h_mirror) (void)hipHostFree(h->h_mirror);
     if (h->h_iter) (void)hipHostFree(h->h_iter);
+    if (h->h_prep) (void)hipHostFree(h->h_prep);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->ev_iter) (void)hipEventDestroy(h->ev_iter);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -2087,27 +2143,28 @@ static reg_status prepare_rowmajor(reg_handle* h, const float* T_init_row, const
     HIPCHK(h, hipSetDevice(h->prm.device));
     std::memcpy(h->T_init, T_init_row, 64);
     const int64_t n = h->n;
-    if (h->prm.cost == REG_COST_P2PL) {
-        if (c_override) {
-            std::memcpy(h->c_read, c_override, 12);
-        } else {
-            s = device_centroid(h, h->s_raw.as<float>(), h->s_stride, n, h->s_misc, h->c_read);
-            if (s != REG_OK) return s;
-        }
-        float A[16], B[16], tmp[16];
-        m4_identity(A);
-        m4_identity(B);
-        for (int k = 0; k < 3; ++k) {
-            A[4 * k + 3] = -h->c_ref[k];   // T_refIn_refMean^-1
-            B[4 * k + 3] = h->c_read[k];   // T_readIn_readMean
-        }
-        m4_mul(A, T_init_row, tmp);
-        m4_mul(tmp, B, h->T0);
-    } else {
-        m4_identity(h->T0);
-    }
     const bool p2pl = h->prm.cost == REG_COST_P2PL;
-    const float* Tkey = p2pl ? h->T0 : T_init_row;
+    // centroid sums -> (device) centroid + T0; the host copy arrives later through the pinned staging buffer and is
+    // only needed for the final composition (R10), so nothing here waits for the device
+    HIPCHK(h, h->s_misc.reserve(256));
+    HIPCHK(h, h->s_prep.reserve(sizeof(PrepState)));
+    if (p2pl && !c_override) {
+        HIPCHK(h, hipMemsetAsync(h->s_misc.p, 0, 3 * sizeof(unsigned long long), h->stream));
+        const int blocks = (int)std::min<int64_t>(1024, (n + 255) / 256);
+        k_centroid_sums<<<blocks, 256, 0, h->stream>>>(h->s_raw.as<float>(), h->s_stride, n,
+                                                       h->s_misc.as<unsigned long long>());
+    }
+    Xf4 Ti;
+    std::memcpy(Ti.m, T_init_row, 64);
+    k_make_T0<<<1, 64, 0, h->stream>>>(h->s_misc.as<unsigned long long>(), n,
+                                       make_float3(h->c_ref[0], h->c_ref[1], h->c_ref[2]), Ti, p2pl ? 1 : 0,
+                                       c_override ? 1 : 0,
+                                       c_override ? make_float3(c_override[0], c_override[1], c_override[2])
+                                                  : make_float3(0.f, 0.f, 0.f),
+                                       h->s_prep.as<PrepState>());
+    HIPCHK(h, hipMemcpyAsync(h->h_prep, h->s_prep.p, sizeof(PrepState), hipMemcpyDeviceToHost, h->stream));
+    h->prep_pending = true;
+    const PrepState* ps = h->s_prep.as<PrepState>();
     h->perm = nullptr;
     if (h->prm.sort_source) {
         const Grid& g = h->grid;
@@ -2115,36 +2172,28 @@ static reg_status prepare_rowmajor(reg_handle* h, const float* T_init_row, const
         HIPCHK(h, h->s_keys2.reserve((size_t)n * 4));
         HIPCHK(h, h->s_perm.reserve((size_t)n * 4));
         HIPCHK(h, h->s_perm2.reserve((size_t)n * 4));
-        int shift = 0;
-        while (std::max(g.dimx, std::max(g.dimy, g.dimz)) / (float)(1 << shift) > 1024.f) ++shift;
-        k_source_keys<<<grid_for(n), 256, 0, h->stream>>>(h->s_raw.as<float>(), h->s_stride, n, h->c_read[0], h->c_read[1],
-                                                          h->c_read[2], make_xf(Tkey), p2pl ? 1 : 0, g.ox, g.oy, g.oz,
-                                                          g.inv_c, g.dimx, g.dimy, g.dimz, shift,
+        // Morton order at brick granularity (7 bits per axis: 3 radix passes instead of 4; finer order buys nothing)
+        int shift = kBrickLog2;
+        while (std::max(g.dimx, std::max(g.dimy, g.dimz)) / (float)(1 << shift) > 128.f) ++shift;
+        k_source_keys<<<grid_for(n), 256, 0, h->stream>>>(h->s_raw.as<float>(), h->s_stride, n, ps, p2pl ? 1 : 0, g.ox, g.oy,
+                                                          g.oz, g.inv_c, g.dimx, g.dimy, g.dimz, shift,
                                                           h->s_keys.as<uint32_t>(), h->s_perm.as<uint32_t>());
         size_t tb = 0;
         HIPCHK(h, rocprim::radix_sort_pairs(nullptr, tb, h->s_keys.as<uint32_t>(), h->s_keys2.as<uint32_t>(),
-                                            h->s_perm.as<uint32_t>(), h->s_perm2.as<uint32_t>(), (size_t)n, 0, 30,
+                                            h->s_perm.as<uint32_t>(), h->s_perm2.as<uint32_t>(), (size_t)n, 0, 21,
                                             h->stream));
         HIPCHK(h, h->s_tmp.reserve(tb));
         HIPCHK(h, rocprim::radix_sort_pairs(h->s_tmp.p, tb, h->s_keys.as<uint32_t>(), h->s_keys2.as<uint32_t>(),
-                                            h->s_perm.as<uint32_t>(), h->s_perm2.as<uint32_t>(), (size_t)n, 0, 30,
+                                            h->s_perm.as<uint32_t>(), h->s_perm2.as<uint32_t>(), (size_t)n, 0, 21,
                                             h->stream));
         h->perm = h->s_perm2.as<uint32_t>();
     }
-    if (p2pl) {
-        k_prepare_source<<<grid_for(n), 256, 0, h->stream>>>(
-            h->s_raw.as<float>(), h->s_stride, h->has_snrm ? h->s_nrm_raw.as<float>() : nullptr, h->s_nstride, n,
-            h->c_read[0], h->c_read[1], h->c_read[2], make_xf(h->T0), 1, h->perm, h->s_xyz.as<float4>(),
-            h->has_snrm ? h->s_nrm.as<float4>() : nullptr);
-    } else {
-        k_prepare_source<<<grid_for(n), 256, 0, h->stream>>>(h->s_raw.as<float>(), h->s_stride, nullptr, 3, n, 0.f, 0.f,
-                                                             0.f, make_xf(h->T0), 0, h->perm, h->s_xyz.as<float4>(),
-                                                             nullptr);
+    k_prepare_source<<<grid_for(n), 256, 0, h->stream>>>(
+        h->s_raw.as<float>(), h->s_stride, (p2pl && h->has_snrm) ? h->s_nrm_raw.as<float>() : nullptr, h->s_nstride, n, ps,
+        p2pl ? 1 : 0, h->perm, h->s_xyz.as<float4>(), (p2pl && h->has_snrm) ? h->s_nrm.as<float4>() : nullptr,
+        h->i_hint.as<uint8_t>(), h->i_hist.as<uint32_t>(), h->i_acc.as<double>(), kAccRows * kSums);
+    if (!p2pl)
         k_pack_cov<<<grid_for(n), 256, 0, h->stream>>>(h->s_cov_raw.as<float>(), n, h->perm, h->s_cov.as<float4>());
-    }
-    HIPCHK(h, hipMemsetAsync(h->i_hint.p, 0, (size_t)n, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->i_hist.p, 0, 3 * 2048 * 4, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->i_acc.p, 0, (size_t)kAccRows * kSums * 8, h->stream));
     HIPCHK(h, hipGetLastError());
     h->prepared = true;
     h->have_match = false;
@@ -2156,8 +2205,9 @@ static reg_status prepare_rowmajor(reg_handle* h, const float* T_init_row, const
 // (Re)initialise the device-side iteration state: pose T (row-major), mode and checker configuration.
 static reg_status init_iter_state(reg_handle* h, const float* T_row, int update) {
     IterState* st = h->h_iter;
-    // the staging copy may still be in flight from a previous call on this stream
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    // the pinned staging copy may still be in flight from the previous call: wait for THAT copy only (an event
+    // recorded right behind it), not for everything else enqueued on the stream
+    if (h->iter_copy_pending) HIPCHK(h, hipEventSynchronize(h->ev_iter));
     std::memset(st, 0, sizeof(IterState));
     for (int i = 0; i < 16; ++i) {
         st->T[i] = T_row[i];
@@ -2182,6 +2232,8 @@ static reg_status init_iter_state(reg_handle* h, const float* T_row, int update)
     st->band_cap = kBandCap;
     st->debug_narrow_band = (h->prm.debug_flags & 8) ? 1 : 0;
     HIPCHK(h, hipMemcpyAsync(h->i_iter.p, st, sizeof(IterState), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipEventRecord(h->ev_iter, h->stream));
+    h->iter_copy_pending = true;
     return REG_OK;
 }
 
@@ -2368,7 +2420,14 @@ static void sums_to_system(const double* sums, bool p2pl, float* H, float* b) {
 }
 
 // R10: T = T_refIn_refMean * T_iter * T_refMean_readMean * T_readIn_readMean^-1 (ICP.cpp:1345); GICP: T_iter itself
-static void compose_rowmajor(const reg_handle* h, const float* T_iter, float* Tout_row) {
+static void compose_rowmajor(reg_handle* h, const float* T_iter, float* Tout_row) {
+    if (h->prep_pending) {
+        // the D2H copy of PrepState was enqueued in reg_prepare; every caller has synchronised the stream since
+        (void)hipStreamSynchronize(h->stream);
+        std::memcpy(h->c_read, h->h_prep->c_read, 12);
+        std::memcpy(h->T0, h->h_prep->T0, 64);
+        h->prep_pending = false;
+    }
     if (h->prm.cost == REG_COST_P2PL) {
         float A[16], B[16], t1[16], t2[16];
         m4_identity(A);
@@ -2459,10 +2518,11 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
     const bool can_fuse = p2pl && h->prm.disable_fused != 1;
     const bool trimming = p2pl && h->prm.use_trimmed && h->prm.trim_ratio != 1.0f;
     const int kGenericFirst = trimming ? 2 : 1;
-    const int kAhead = fixed > 0 ? 4 : 2;
+    const int kAhead = getenv("O3D_KAHEAD") ? atoi(getenv("O3D_KAHEAD")) : (fixed > 0 ? 3 : 2);
     const HostMirror* mir = h->h_mirror;
     int generic_left = kGenericFirst;
     const bool trace = getenv("O3D_TRACE") != nullptr;
+    const float settle_tol = getenv("O3D_SETTLE") ? (float)atof(getenv("O3D_SETTLE")) : 0.05f;
     unsigned long long last_traced = 0;
     unsigned long long acked = seq0;   // every sequence <= acked has either reported or been a no-op
     int stalls = 0;
@@ -2493,7 +2553,7 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
             bool settled = true;
             if (trimming) {
                 settled = any && mir->limit_prev < INFINITY && mir->limit_last < INFINITY &&
-                          std::fabs(mir->limit_last - mir->limit_prev) <= 0.05f * mir->limit_last;
+                          std::fabs(mir->limit_last - mir->limit_prev) <= settle_tol * mir->limit_last;
             }
             if (!can_fuse || generic_left > 0 || !settled) {
                 s = enqueue_iteration(h, false);
