@@ -2556,10 +2556,10 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
                           std::fabs(mir->limit_last - mir->limit_prev) <= settle_tol * mir->limit_last;
             }
             if (!can_fuse || generic_left > 0 || !settled) {
-                s = enqueue_iteration(h, false);
+                s = enqueue_iteration(h, true);   // weights are always written: reg_get_correspondences reports them
                 if (generic_left > 0) --generic_left;
             } else {
-                s = enqueue_fused(h, false);
+                s = enqueue_fused(h, true);
             }
             if (s != REG_OK) return s;
             continue;
