@@ -191,6 +191,25 @@ REG_API reg_status reg_dist_buffers(reg_handle* h, void** hist, void** sums);
 REG_API reg_status reg_dist_phase(reg_handle* h, int phase);
 REG_API reg_status reg_dist_finish(reg_handle* h, float T_out[16], reg_result* res);
 
+/* Fused multi-GPU iteration (2 launches + ONE all-gather per iteration instead of 6 launches + 4 all-reduces), usable
+   once the trimmed limit has settled -- same prediction / exact verification as the single-GPU fused iteration:
+   phase 5: fused search + weights + normal equations on this rank's slice; its certain sums, band count and band
+            records (<= 512) go into a fixed-size contribution block            -> all-gather(contrib -> gathered)
+   phase 6: every rank reduces the SAME gathered blocks in rank order (identical results, no broadcast), verifies the
+            band with the global counts, selects the exact global quantile, solves and updates on the device.
+   A failed verification (or an overflowing block) sets `stall` on every rank alike; the caller then runs that
+   iteration through phases 0-4. */
+typedef struct {
+    int64_t sequences_done;      /* update kernels that have reported since reg_dist_begin */
+    int64_t sequences_enqueued;
+    int32_t iterations;          /* completed Gauss-Newton iterations */
+    int32_t done, stall, stream_idle;
+    float   limit_last, limit_prev;
+} reg_dist_status;
+REG_API reg_status reg_dist_fused_buffers(reg_handle* h, int n_ranks, int rank, void** contrib, void** gathered,
+                                          int64_t* contrib_bytes);
+REG_API reg_status reg_dist_poll(reg_handle* h, reg_dist_status* out);
+
 /* Host-side pieces of the path, exported so they can be checked without a GPU
    (PointToPlane.cpp:112-265 solve, :327-381 x -> 4x4; column-major 4x4). */
 REG_API int  reg_host_solve6(const float A[36], const float b[6], float x[6]);

@@ -45,6 +45,12 @@ class RegResult(C.Structure):
                 ("prof_ms", C.c_float * 4), ("prof_launches", C.c_int32 * 4)]
 
 
+class DistStatus(C.Structure):
+    _fields_ = [("sequences_done", C.c_int64), ("sequences_enqueued", C.c_int64), ("iterations", C.c_int32),
+                ("done", C.c_int32), ("stall", C.c_int32), ("stream_idle", C.c_int32), ("limit_last", C.c_float),
+                ("limit_prev", C.c_float)]
+
+
 class TargetInfo(C.Structure):
     _fields_ = [("n_points", C.c_int64), ("n_bricks", C.c_int64), ("n_cells_occupied", C.c_int64),
                 ("table_bytes", C.c_int64), ("cell_size", C.c_float), ("origin", C.c_float * 3),
@@ -55,7 +61,8 @@ EXPORTS = ["reg_default_params", "reg_shipped_params", "reg_create", "reg_destro
            "reg_set_stream", "reg_set_target", "reg_set_source", "reg_register", "reg_compute", "reg_prepare",
            "reg_linearize", "reg_get_correspondences", "reg_match_local", "reg_trim_histogram", "reg_reduce_local",
            "reg_solve_update", "reg_host_solve6", "reg_host_x_to_T", "reg_host_centroid", "reg_get_target_info", "reg_profile_kernels", "reg_source_centroid_sums", "reg_prepare_centroid", "reg_compose",
-           "reg_dist_begin", "reg_dist_buffers", "reg_dist_phase", "reg_dist_finish"]
+           "reg_dist_begin", "reg_dist_buffers", "reg_dist_phase", "reg_dist_finish",
+           "reg_dist_fused_buffers", "reg_dist_poll"]
 
 
 def lib_path() -> str:
@@ -117,6 +124,8 @@ def load_library():
     lib.reg_dist_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     lib.reg_dist_phase.argtypes = [vp, C.c_int]
     lib.reg_dist_finish.argtypes = [vp, f32p, C.POINTER(RegResult)]
+    lib.reg_dist_fused_buffers.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int64)]
+    lib.reg_dist_poll.argtypes = [vp, C.POINTER(DistStatus)]
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError if the library does not export what the header declares
     _lib = lib
@@ -290,6 +299,17 @@ class Registration:
         hp, sp = C.c_void_p(), C.c_void_p()
         self._check(self._lib.reg_dist_buffers(self._h, C.byref(hp), C.byref(sp)))
         return hp.value, sp.value
+
+    def dist_fused_buffers(self, n_ranks, rank):
+        """(contrib_ptr, gathered_ptr, contrib_bytes) of the fused multi-GPU iteration."""
+        cp, gp, nb = C.c_void_p(), C.c_void_p(), C.c_int64()
+        self._check(self._lib.reg_dist_fused_buffers(self._h, n_ranks, rank, C.byref(cp), C.byref(gp), C.byref(nb)))
+        return cp.value, gp.value, nb.value
+
+    def dist_poll(self):
+        st = DistStatus()
+        self._check(self._lib.reg_dist_poll(self._h, C.byref(st)))
+        return st
 
     def dist_phase(self, phase):
         self._check(self._lib.reg_dist_phase(self._h, phase))

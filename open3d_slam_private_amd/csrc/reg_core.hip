@@ -903,6 +903,11 @@ k_linearize_gicp(const float4* __restrict__ src, const float4* __restrict__ src_
 // the queue; the host re-runs that iteration on the generic (select-based) path.  Results are identical to
 // the generic path by construction: same products, same fp64 accumulation, exact quantile.
 constexpr int kBandCap = 16384;
+// Multi-GPU fused iteration: every rank contributes one fixed-size block {32 double sums, band count, up to
+// kContribCap band records}; ONE all-gather per iteration hands every rank all blocks.
+constexpr int kContribHdr = 128;                       // floats: [0..63] = 32 doubles, [64] = band count (uint32 bits)
+constexpr int kContribCap = 512;                       // band records per rank
+constexpr int kContribFloats = kContribHdr + kContribCap * 32;
 constexpr int kAccRows = 64;   // replicas of the 32-double accumulator (spreads the fp64 atomics)
 constexpr int kRec = 32;   // floats per band record
 // Band buffer layout: record-major band[slot][kRec] (component-major, with or without a padded pitch, measured
@@ -946,7 +951,7 @@ __global__ void __launch_bounds__(256)
 k_iter_fused(const float4* __restrict__ src, const float4* __restrict__ src_nrm, int64_t n, IterState* __restrict__ it,
              Grid g, const float4* __restrict__ tgt_nrm, FilterCfg f, int* __restrict__ pos_out,
              float* __restrict__ d2_out, float* __restrict__ w_out, uint8_t* __restrict__ hint,
-             float* __restrict__ band, double* __restrict__ partials, int n_blocks) {
+             float* __restrict__ band, int band_cap, double* __restrict__ partials, int n_blocks) {
     constexpr int CP = kSums / G;   // components owned by each lane of a group
     __shared__ double sh[4][kSums];
     if (it->done || it->stall) return;
@@ -998,7 +1003,7 @@ k_iter_fused(const float4* __restrict__ src, const float4* __restrict__ src_nrm,
             if (cls == 1 && sub == 0) {
                 // band record: decided by the update kernel
                 const unsigned slot = atomicAdd(&it->band_count, 1u);
-                if (slot < (unsigned)kBandCap) {
+                if (slot < (unsigned)band_cap) {
 #pragma unroll
                     for (int k = 0; k < 31; ++k)
                         if (k != 29) band[band_at(k, slot)] = vals[k];
@@ -1083,6 +1088,28 @@ __device__ __forceinline__ void block_pick1024(const uint32_t* h, int nb, uint32
 // predicted trimmed band + exact quantile inside it + the surviving band records; then (it->update) R8 + R9 on
 // the device -- 6x6 solve in fp64, x -> 4x4, T_iter <- dT * T_iter, transformation checkers -- and a mirror of
 // the outcome into mapped host memory followed by a sequence word the host polls.
+// Multi-GPU fused iteration, between the fused kernel and the all-gather: reduce this rank's accumulator replicas
+// into the header of its contribution block (and clear them), record its band count.
+__global__ void __launch_bounds__(64)
+k_pack_contrib(double* __restrict__ acc, const IterState* __restrict__ it, float* __restrict__ contrib) {
+    const int c = threadIdx.x;
+    double* hdr = reinterpret_cast<double*>(contrib);
+    if (it->done || it->stall) {
+        if (c < kSums) hdr[c] = 0.0;
+        if (c == 0) reinterpret_cast<uint32_t*>(contrib)[64] = 0u;
+        return;
+    }
+    if (c < kSums) {
+        double t = 0;
+        for (int r = 0; r < kAccRows; ++r) {
+            t += acc[(size_t)r * kSums + c];
+            acc[(size_t)r * kSums + c] = 0.0;
+        }
+        hdr[c] = t;
+    }
+    if (c == 0) reinterpret_cast<uint32_t*>(contrib)[64] = it->band_count;
+}
+
 // Workgroup barrier that only waits for LDS traffic: global loads issued earlier stay in flight across it
 // (__syncthreads() drains vmcnt(0) first -- cdna_hip_programming.md, "Pipelining across barriers").
 __device__ __forceinline__ void lds_barrier() {
@@ -1093,7 +1120,7 @@ __device__ __forceinline__ void lds_barrier() {
 __global__ void __launch_bounds__(1024)
 k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it, HostMirror* host,
                 unsigned long long seq, int fused, const float* __restrict__ band, float* __restrict__ w_out,
-                const SelectState* __restrict__ sel) {
+                const SelectState* __restrict__ sel, const float* __restrict__ gathered, int n_ranks, int my_rank) {
     __shared__ double sh[32][kSums];
     __shared__ double tot[kSums];
     __shared__ uint32_t hist[2048 + 64];
@@ -1104,18 +1131,46 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
     __shared__ __attribute__((aligned(16))) uint32_t mir_w[(sizeof(HostMirror) + 3) / 4];
     __shared__ uint32_t small[64];
     __shared__ uint32_t s_cnt, s_csel, s_need_radix;
+    __shared__ uint32_t rk_off[65];   // multi-GPU: first global band index of every rank's records (+ total)
+    __shared__ uint32_t rk_bad;
     // read every state field this kernel branches on in ONE batch (each separate use would cost an L2 round trip)
     const int s_done = it->done, s_stall = it->stall, s_use_trim = it->use_trim;
     const float s_ratio = it->trim_ratio, s_band_lo = it->band_lo, s_band_hi = it->band_hi;
-    const uint32_t s_band_count = it->band_count;
+    uint32_t s_band_count = it->band_count;
+    bool band_bad = false;   // a band buffer overflowed: the prediction cannot be verified
     if (s_done) return;
     if (fused && s_stall) return;
     const unsigned long long st0 = __builtin_amdgcn_s_memtime();
     const int comp = threadIdx.x & (kSums - 1), part = threadIdx.x / kSums;  // 32 parts x 32 comps
+    if (gathered) {
+        // every rank sees the same blocks in the same order -> identical results everywhere, no broadcast needed
+        if (threadIdx.x == 0) {
+            uint32_t off = 0, bad = 0;
+            for (int r = 0; r < n_ranks; ++r) {
+                rk_off[r] = off;
+                const uint32_t cnt = reinterpret_cast<const uint32_t*>(gathered + (size_t)r * kContribFloats)[64];
+                if (cnt > (uint32_t)kContribCap) bad = 1;
+                off += min(cnt, (uint32_t)kContribCap);
+            }
+            rk_off[n_ranks] = off;
+            rk_bad = bad;
+        }
+        __syncthreads();
+        s_band_count = rk_off[n_ranks];
+        band_bad = rk_bad != 0;
+    }
+    if (!gathered && s_band_count > (uint32_t)kBandCap) band_bad = true;
+    // record (i, component c) of the band, whichever buffer holds it
+    auto rec = [&](uint32_t i, int c) -> float {
+        if (!gathered) return band[band_at(c, i)];
+        int r = 0;
+        while (r + 1 < n_ranks && i >= rk_off[r + 1]) ++r;
+        return gathered[(size_t)r * kContribFloats + kContribHdr + (size_t)(i - rk_off[r]) * kRec + c];
+    };
     // fused path: issue this thread's band-record loads right away (they only depend on the record count); the
     // barriers below are LDS-only, so the loads stay in flight behind the partial sums
     const bool trim = s_use_trim && s_ratio != 1.0f;
-    const uint32_t n_band = (fused && trim) ? min(s_band_count, (uint32_t)kBandCap) : 0u;
+    const uint32_t n_band = (fused && trim && !band_bad) ? s_band_count : 0u;
     const bool add_comp = comp != 29 && comp != 31;
     float pre[16];
     uint32_t my_d2[kBandCap / 1024];
@@ -1123,16 +1178,19 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
 #pragma unroll
         for (int u = 0; u < kBandCap / 1024; ++u) {
             const uint32_t i = threadIdx.x + 1024u * u;
-            my_d2[u] = i < n_band ? __float_as_uint(band[band_at(29, i)]) : 0u;
+            my_d2[u] = i < n_band ? __float_as_uint(rec(i, 29)) : 0u;
         }
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             const uint32_t i = min((uint32_t)part + 32u * u, n_band - 1);
-            pre[u] = add_comp ? band[band_at(comp, i)] : 0.f;
+            pre[u] = add_comp ? rec(i, comp) : 0.f;
         }
     }
     double t = 0;
-    if (fused) {
+    if (gathered) {
+        for (int r = part; r < n_ranks; r += 32)
+            t += reinterpret_cast<const double*>(gathered + (size_t)r * kContribFloats)[comp];
+    } else if (fused) {
         for (int b = part; b < kAccRows; b += 32) {
             t += partials[(size_t)b * kSums + comp];
             const_cast<double*>(partials)[(size_t)b * kSums + comp] = 0.0;   // ready for the next iteration
@@ -1157,7 +1215,7 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
         // ---- verify the predicted band with exact counts, then select the exact quantile inside it
         const uint32_t n_finite = (uint32_t)llround(tot[29]), n_below = (uint32_t)llround(tot[31]);
         const uint32_t k = trim_rank(n_finite, s_ratio);
-        const bool ok = n_finite == 0 || (s_band_count <= (uint32_t)kBandCap && n_below <= k && k < n_below + n_band);
+        const bool ok = n_finite == 0 || (!band_bad && n_below <= k && k < n_below + n_band);
         if (!ok) {
             if (threadIdx.x == 0) {
                 it->stall = 1;
@@ -1281,7 +1339,7 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
 #pragma unroll
                     for (int u = 0; u < 16; ++u) {
                         const uint32_t i = min(i0 + 32u * u, n_band - 1);
-                        vv[u] = band[band_at(comp, i)];
+                        vv[u] = rec(i, comp);
                     }
 #pragma unroll
                     for (int u = 0; u < 16; ++u) {
@@ -1293,7 +1351,13 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
             sh[part][comp] = acc;
             if (w_out)
                 for (uint32_t i = threadIdx.x; i < n_band; i += 1024) {
-                    if (!(__uint_as_float(bd2[i]) <= limit)) w_out[__float_as_int(band[band_at(31, i)])] = 0.f;
+                    if (!(__uint_as_float(bd2[i]) <= limit)) {
+                        if (!gathered) {
+                            w_out[__float_as_int(rec(i, 31))] = 0.f;
+                        } else if (i >= rk_off[my_rank] && i < rk_off[my_rank + 1]) {
+                            w_out[__float_as_int(rec(i, 31))] = 0.f;   // only this rank's own points
+                        }
+                    }
                 }
             __syncthreads();
             if (threadIdx.x < kSums) {
@@ -1580,6 +1644,8 @@ struct reg_handle {
     const uint32_t* perm = nullptr;   // slot -> input index (null: identity)
     int last_stalls = 0;
     unsigned long long dist_seq0 = 0;
+    DevBuf d_contrib, d_gathered;     // multi-GPU fused iteration: this rank's block / all ranks' blocks
+    int dist_ranks = 0, dist_rank = 0;
     // loop profiling (params.profile_loop): HIP events around the search kernels of every iteration
     std::vector<hipEvent_t> prof_ev;   // pairs (start, stop)
     std::vector<int> prof_kind;        // 0: k_match, 1: k_iter_fused
@@ -1689,7 +1755,7 @@ void reg_destroy(reg_handle* h) {
                       &h->t_vals2, &h->t_pts, &h->t_nrm, &h->t_cov, &h->t_flags, &h->t_scan, &h->t_hash, &h->t_cells,
                       &h->t_tmp, &h->t_misc, &h->s_raw, &h->s_nrm_raw, &h->s_cov_raw, &h->s_xyz, &h->s_nrm, &h->s_cov,
                       &h->s_misc, &h->i_pos, &h->i_d2, &h->i_w, &h->i_hist, &h->i_state, &h->i_partials, &h->i_sums,
-                      &h->i_ids, &h->s_prep, &h->i_iter, &h->t_halo_start, &h->t_halo_cursor, &h->t_halo_pts, &h->i_band, &h->i_acc, &h->i_hint, &h->s_keys, &h->s_keys2, &h->s_perm, &h->s_perm2, &h->s_tmp, &h->i_tmpf};
+                      &h->i_ids, &h->d_contrib, &h->d_gathered, &h->s_prep, &h->i_iter, &h->t_halo_start, &h->t_halo_cursor, &h->t_halo_pts, &h->i_band, &h->i_acc, &h->i_hint, &h->s_keys, &h->s_keys2, &h->s_perm, &h->s_perm2, &h->s_tmp, &h->i_tmpf};
     for (DevBuf* b : bufs) b->release();
     if (h->h_mirror) (void)hipHostFree(h->h_mirror);
     if (h->h_iter) (void)hipHostFree(h->h_iter);
@@ -2320,7 +2386,8 @@ static reg_status enqueue_linearize(reg_handle* h, bool want_w, bool limit_from_
     ++h->seq;
     k_reduce_update<<<1, 1024, 0, h->stream>>>(h->i_partials.as<double>(), h->n_blocks, h->i_iter.as<IterState>(),
                                                h->d_mirror, h->seq, 0, nullptr, nullptr,
-                                               h->prm.cost == REG_COST_P2PL ? h->i_state.as<SelectState>() : nullptr);
+                                               h->prm.cost == REG_COST_P2PL ? h->i_state.as<SelectState>() : nullptr,
+                                               nullptr, 0, 0);
     return REG_OK;
 }
 
@@ -2344,12 +2411,12 @@ static void launch_fused(reg_handle* h, const FilterCfg& f, float* w, uint8_t* h
     prof_mark(h, 1, true);
     k_iter_fused<G><<<8 * ((blocks + 7) / 8), 256, 0, h->stream>>>(
         h->s_xyz.as<float4>(), h->has_snrm ? h->s_nrm.as<float4>() : nullptr, h->n, h->i_iter.as<IterState>(), h->grid,
-        h->t_nrm.as<float4>(), f, h->i_pos.as<int>(), h->i_d2.as<float>(), w, hint, h->i_band.as<float>(),
+        h->t_nrm.as<float4>(), f, h->i_pos.as<int>(), h->i_d2.as<float>(), w, hint, h->i_band.as<float>(), kBandCap,
         h->i_acc.as<double>(), blocks);
     prof_mark(h, 1, false);
     ++h->seq;
     k_reduce_update<<<1, 1024, 0, h->stream>>>(h->i_acc.as<double>(), blocks, h->i_iter.as<IterState>(), h->d_mirror,
-                                               h->seq, 1, h->i_band.as<float>(), w, nullptr);
+                                               h->seq, 1, h->i_band.as<float>(), w, nullptr, nullptr, 0, 0);
 }
 
 static reg_status enqueue_fused(reg_handle* h, bool want_w) {
@@ -2803,6 +2870,43 @@ reg_status reg_dist_buffers(reg_handle* h, void** hist, void** sums) {
     return REG_OK;
 }
 
+// Buffers of the fused multi-GPU iteration (phases 5 and 6): `contrib` is this rank's block (contrib_bytes), `gathered`
+// receives the blocks of all `n_ranks` ranks in rank order (one all-gather between phase 5 and phase 6).
+reg_status reg_dist_fused_buffers(reg_handle* h, int n_ranks, int rank, void** contrib, void** gathered,
+                                  int64_t* contrib_bytes) {
+    if (!h || !contrib || !gathered || !contrib_bytes || n_ranks < 1 || n_ranks > 64 || rank < 0 || rank >= n_ranks)
+        return REG_BAD_ARGUMENT;
+    if (h->n == 0) return REG_NOT_CONFIGURED;
+    HIPCHK(h, hipSetDevice(h->prm.device));
+    HIPCHK(h, h->d_contrib.reserve((size_t)kContribFloats * 4));
+    HIPCHK(h, h->d_gathered.reserve((size_t)n_ranks * kContribFloats * 4));
+    HIPCHK(h, hipMemsetAsync(h->d_contrib.p, 0, (size_t)kContribFloats * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_gathered.p, 0, (size_t)n_ranks * kContribFloats * 4, h->stream));
+    h->dist_ranks = n_ranks;
+    h->dist_rank = rank;
+    *contrib = h->d_contrib.p;
+    *gathered = h->d_gathered.p;
+    *contrib_bytes = (int64_t)kContribFloats * 4;
+    return REG_OK;
+}
+
+// Non-blocking view of the mirror the update kernel writes (the stream-ordered drivers steer by it).
+reg_status reg_dist_poll(reg_handle* h, reg_dist_status* out) {
+    if (!h || !out) return REG_BAD_ARGUMENT;
+    const HostMirror* mir = h->h_mirror;
+    const unsigned long long s = mirror_seq(h);
+    out->sequences_done = s > h->dist_seq0 ? (int64_t)(s - h->dist_seq0) : 0;
+    out->sequences_enqueued = (int64_t)(h->seq - h->dist_seq0);
+    const bool any = s > h->dist_seq0;
+    out->iterations = any ? mir->iterations : 0;
+    out->done = any ? mir->done : 0;
+    out->stall = any ? mir->stall : 0;
+    out->limit_last = any ? mir->limit_last : INFINITY;
+    out->limit_prev = any ? mir->limit_prev : INFINITY;
+    out->stream_idle = hipStreamQuery(h->stream) == hipSuccess ? 1 : 0;
+    return REG_OK;
+}
+
 reg_status reg_dist_phase(reg_handle* h, int phase) {
     reg_status s = check_ready(h, true);
     if (s != REG_OK) return s;
@@ -2847,7 +2951,31 @@ reg_status reg_dist_phase(reg_handle* h, int phase) {
             ++h->seq;
             k_reduce_update<<<1, 1024, 0, h->stream>>>(h->i_sums.as<double>(), 1, h->i_iter.as<IterState>(), h->d_mirror,
                                                        h->seq, 0, nullptr, nullptr,
-                                                       h->prm.cost == REG_COST_P2PL ? st : nullptr);
+                                                       h->prm.cost == REG_COST_P2PL ? st : nullptr, nullptr, 0, 0);
+            break;
+        case 5: {
+            // fused iteration, local half: search + weights + normal equations + band records (into this rank's
+            // contribution block), then the block header.  Followed by the caller's ONE all-gather.
+            if (h->prm.cost != REG_COST_P2PL || h->dist_ranks <= 0) return REG_BAD_ARGUMENT;
+            const FilterCfg f = make_filter_cfg(h, 0);
+            uint8_t* hint = h->prm.match_variant == 2 ? nullptr : h->i_hint.as<uint8_t>();
+            const int blocks = grid_for(h->n * 8);
+            float* contrib = h->d_contrib.as<float>();
+            k_iter_fused<8><<<8 * ((blocks + 7) / 8), 256, 0, h->stream>>>(
+                h->s_xyz.as<float4>(), h->has_snrm ? h->s_nrm.as<float4>() : nullptr, h->n, h->i_iter.as<IterState>(),
+                h->grid, h->t_nrm.as<float4>(), f, h->i_pos.as<int>(), h->i_d2.as<float>(), h->i_w.as<float>(), hint,
+                contrib + kContribHdr, kContribCap, h->i_acc.as<double>(), blocks);
+            k_pack_contrib<<<1, 64, 0, h->stream>>>(h->i_acc.as<double>(), it, contrib);
+            h->have_match = true;
+            break;
+        }
+        case 6:
+            // fused iteration, global half: every rank reduces the SAME gathered blocks in the same order
+            if (h->dist_ranks <= 0) return REG_BAD_ARGUMENT;
+            ++h->seq;
+            k_reduce_update<<<1, 1024, 0, h->stream>>>(nullptr, 0, h->i_iter.as<IterState>(), h->d_mirror, h->seq, 1,
+                                                       nullptr, h->i_w.as<float>(), nullptr, h->d_gathered.as<float>(),
+                                                       h->dist_ranks, h->dist_rank);
             break;
         default:
             return REG_BAD_ARGUMENT;

@@ -139,3 +139,91 @@ class StreamDistributedRegistration:
             self._ar(self.sums)
             reg.dist_phase(4)
         return reg.dist_finish()
+
+
+class FusedStreamDistributedRegistration(StreamDistributedRegistration):
+    """Stream-ordered multi-GPU loop that switches, once the trimmed limit has settled, from the select-based
+    iteration (6 launches + 4 all-reduces) to the fused iteration (2 launches + ONE all-gather of a 66 KB block per
+    rank).  The device decides whether a fused iteration was valid (exact verification of the predicted band, on
+    every rank alike); a stalled iteration is repeated on the select-based path.  The host steers by the mirror the
+    update kernel writes (reg_dist_poll) and stays at most `ahead` iterations ahead of it."""
+
+    def __init__(self, reg, use_trimmed, trim_ratio, iters, world, rank, dist=None, device=None, all_reduce=None,
+                 all_gather=None, ahead=3, fixed=True, settle_tol=0.05):
+        super().__init__(reg, use_trimmed, iters, dist=dist, device=device, all_reduce=all_reduce)
+        import torch
+        self.world, self.rank, self.ahead, self.fixed, self.settle_tol = world, rank, ahead, fixed, settle_tol
+        self.trimming = bool(use_trimmed) and float(np.float32(trim_ratio)) != 1.0
+        cp, gp, nbytes = reg.dist_fused_buffers(world, rank)
+        dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        n = nbytes // 4
+        self.contrib = torch.as_tensor(_DevArray(cp, (n,), "<f4"), device=dev)
+        self.gathered = torch.as_tensor(_DevArray(gp, (world * n,), "<f4"), device=dev)
+        if all_gather is not None:
+            self._ag = all_gather
+        elif dist is not None and world > 1:
+            self._ag = lambda out, inp: dist.all_gather_into_tensor(out, inp)
+        else:
+            self._ag = lambda out, inp: out.copy_(inp)
+        self.n_fused = self.n_generic = self.n_stalls = 0
+
+    def _generic(self):
+        reg = self.reg
+        reg.dist_phase(0)
+        if self.use_trimmed:
+            self._ar(self.hist[0])
+            reg.dist_phase(1)
+            self._ar(self.hist[1])
+            reg.dist_phase(2)
+            self._ar(self.hist[2])
+        reg.dist_phase(3)
+        self._ar(self.sums)
+        reg.dist_phase(4)
+        self.n_generic += 1
+
+    def _fused(self):
+        self.reg.dist_phase(5)
+        self._ag(self.gathered, self.contrib)
+        self.reg.dist_phase(6)
+        self.n_fused += 1
+
+    def run(self, T_start=None):
+        reg = self.reg
+        reg.dist_begin(T_start)
+        limit = self.iters
+        generic_left = 2 if self.trimming else 1
+        acked = 0          # sequences (1 per enqueued iteration) accounted for: reported or known no-ops
+        enq = 0
+        while True:
+            st = reg.dist_poll()
+            done_seq = int(st.sequences_done)
+            if done_seq > 0 and st.done:
+                break
+            if done_seq > 0 and st.stall and done_seq > acked:
+                # the band prediction failed at sequence `done_seq`: what is enqueued behind it are no-ops
+                while not reg.dist_poll().stream_idle:
+                    pass
+                acked = enq
+                generic_left = 2
+                self.n_stalls += 1
+                continue
+            acked = max(acked, done_seq)
+            completed = int(st.iterations) if done_seq > 0 else 0
+            inflight = enq - acked
+            if completed + inflight < limit and inflight < self.ahead:
+                settled = True
+                if self.trimming:
+                    settled = (done_seq > 0 and math.isfinite(st.limit_prev) and math.isfinite(st.limit_last) and
+                               abs(st.limit_last - st.limit_prev) <= self.settle_tol * st.limit_last)
+                if generic_left > 0 or not settled:
+                    self._generic()
+                    generic_left = max(generic_left - 1, 0)
+                else:
+                    self._fused()
+                enq += 1
+                continue
+            if inflight == 0:
+                break
+            if st.stream_idle and int(reg.dist_poll().sequences_done) <= acked:
+                acked = enq    # drained without a report: no-ops after `done`
+        return reg.dist_finish()
