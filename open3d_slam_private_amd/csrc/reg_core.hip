@@ -20,6 +20,11 @@
 
 using namespace o3dreg;
 
+// minimum waves per SIMD the search kernels are compiled for (2nd __launch_bounds__ argument): caps their VGPRs
+#ifndef O3D_MATCH_WAVES
+#define O3D_MATCH_WAVES 1
+#endif
+
 // Iteration state living in device memory: the pose the kernels read, the checker history and the
 // termination flags.  The update kernel (last kernel of an iteration) is its only writer, so a whole
 // registration can be enqueued without a host round trip per Gauss-Newton iteration.
@@ -405,7 +410,7 @@ k_match(const float4* __restrict__ src, int64_t n, const IterState* __restrict__
 // Cooperative variant: G (8 or 4) lanes per reading point (256/G points per 256-thread workgroup).
 // `hint` (one byte per point, may be null) carries the terminating level of the previous iteration.
 template <int G>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, O3D_MATCH_WAVES)
 k_match_g8(const float4* __restrict__ src, int64_t n, const IterState* __restrict__ it, Grid g, int* __restrict__ pos,
            float* __restrict__ d2, uint32_t* __restrict__ hist0 /* 2048 or null */,
            uint32_t* __restrict__ hist2_to_zero, uint8_t* __restrict__ hint, int shift0, int debug, int n_blocks) {
@@ -947,7 +952,7 @@ __device__ __forceinline__ void p2pl_products(float3 p, float4 q, float4 nn, flo
 }
 
 template <int G>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, O3D_MATCH_WAVES)
 k_iter_fused(const float4* __restrict__ src, const float4* __restrict__ src_nrm, int64_t n, IterState* __restrict__ it,
              Grid g, const float4* __restrict__ tgt_nrm, FilterCfg f, int* __restrict__ pos_out,
              float* __restrict__ d2_out, float* __restrict__ w_out, uint8_t* __restrict__ hint,
