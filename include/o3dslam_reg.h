@@ -220,6 +220,27 @@ REG_API void reg_host_centroid(const float* xyz, int64_t stride, int64_t n, floa
    stream, of [0] the match kernel, [1] the trimmed-quantile select passes, [2] linearize + final reduce. */
 REG_API reg_status reg_profile_kernels(reg_handle* h, const float T_iter[16], int reps, float ms[3]);
 
+/* ---- next row: surface normals / covariances by exact k-NN + PCA ------------------------------
+   Replaces the CPU producers of the attributes the registration consumes:
+     libpointmatcher/pointmatcher/DataPointsFilters/SurfaceNormal.cpp:152-252  (SurfaceNormalDataPointsFilter:
+       self k-NN including the point itself, mean, C = NN NN^T, eigenvector of the smallest eigenvalue, clamped to
+       [-1,1]; a neighbourhood of rank < 2 yields the zero vector),
+     open3d_slam/src/CloudRegistration.cpp:25-43  (estimateNormals(KDTreeSearchParamKNN) +
+       OrientNormalsTowardsCameraLocation before every point-to-plane registration),
+     open3d_slam/src/helpers.cpp:153-165           (the same with a radius cap).
+   xyz: n points, stride in floats.  k in [1,32] neighbours (the point itself counts), max_dist > 0 (may be +inf).
+   viewpoint: NULL -> sign such that the largest component is positive; else normals face the viewpoint.
+   Outputs (host pointers, or device pointers when on_device != 0), indexed like the input:
+     normals  n x 3 (required);  eigvals n x 3 ascending (may be NULL);
+     covs     n x 6 {xx xy xz yy yz zz} (may be NULL): C/m, or with regularise != 0 the plane-like GICP covariance
+              V diag(1e-3,1,1) V^T (small_gicp / Open3D GICP convention);
+     ids      n x k neighbour indices ascending by (d2, index), -1 padded (may be NULL).
+   n_rescanned (may be NULL): points whose candidate list exceeded the on-chip list (statistics; results are exact). */
+REG_API reg_status reg_estimate_normals(reg_handle* h, const float* xyz, int64_t xyz_stride, int64_t n, int on_device,
+                                        int k, float max_dist, const float viewpoint[3], int regularise,
+                                        float* normals, float* eigvals, float* covs, int32_t* ids,
+                                        int64_t* n_rescanned);
+
 /* Introspection of the search structure (tests, DESIGN.md numbers). */
 typedef struct {
     int64_t n_points;

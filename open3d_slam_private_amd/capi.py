@@ -62,7 +62,7 @@ EXPORTS = ["reg_default_params", "reg_shipped_params", "reg_create", "reg_destro
            "reg_linearize", "reg_get_correspondences", "reg_match_local", "reg_trim_histogram", "reg_reduce_local",
            "reg_solve_update", "reg_host_solve6", "reg_host_x_to_T", "reg_host_centroid", "reg_get_target_info", "reg_profile_kernels", "reg_source_centroid_sums", "reg_prepare_centroid", "reg_compose",
            "reg_dist_begin", "reg_dist_buffers", "reg_dist_phase", "reg_dist_finish",
-           "reg_dist_fused_buffers", "reg_dist_poll"]
+           "reg_dist_fused_buffers", "reg_dist_poll", "reg_estimate_normals"]
 
 
 def lib_path() -> str:
@@ -126,6 +126,8 @@ def load_library():
     lib.reg_dist_finish.argtypes = [vp, f32p, C.POINTER(RegResult)]
     lib.reg_dist_fused_buffers.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int64)]
     lib.reg_dist_poll.argtypes = [vp, C.POINTER(DistStatus)]
+    lib.reg_estimate_normals.argtypes = [vp, vp, i64, i64, C.c_int, C.c_int, C.c_float, vp, C.c_int, vp, vp, vp, vp,
+                                         C.POINTER(C.c_int64)]
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError if the library does not export what the header declares
     _lib = lib
@@ -221,6 +223,38 @@ class Registration:
         self._check(self._lib.reg_set_source(self._h, _ptr(xyz), xyz.shape[1] if xyz.ndim == 2 else 3, _ptr(nrm),
                                              nrm.shape[1] if nrm is not None else 3, _ptr(cov), n, 0))
         self.n_source = n
+
+    def estimate_normals(self, xyz, k=10, max_dist=np.inf, viewpoint=None, regularise=False, want_eigvals=False,
+                         want_covs=False, want_ids=False):
+        """Exact k-NN + PCA normals (SurfaceNormal.cpp:152-252 / CloudRegistration.cpp:25-43).  Returns a dict with
+        `normals` (n,3) and, on request, `eigvals` (n,3), `covs` (n,6), `ids` (n,k), plus `n_rescanned`."""
+        xyz = _f32(xyz)
+        n = xyz.shape[0] if xyz.ndim == 2 else 0
+        out = {"normals": np.zeros((n, 3), np.float32)}
+        if want_eigvals:
+            out["eigvals"] = np.zeros((n, 3), np.float32)
+        if want_covs:
+            out["covs"] = np.zeros((n, 6), np.float32)
+        if want_ids:
+            out["ids"] = np.zeros((n, k), np.int32)
+        vp_ = _f32(viewpoint) if viewpoint is not None else None
+        resc = C.c_int64(0)
+        self._check(self._lib.reg_estimate_normals(
+            self._h, _ptr(xyz), xyz.shape[1] if xyz.ndim == 2 else 3, n, 0, int(k), float(max_dist), _ptr(vp_),
+            1 if regularise else 0, _ptr(out["normals"]), _ptr(out.get("eigvals")), _ptr(out.get("covs")),
+            _ptr(out.get("ids")), C.byref(resc)))
+        out["n_rescanned"] = int(resc.value)
+        return out
+
+    def estimate_normals_device(self, xyz_ptr, xyz_stride, n, normals_ptr, k=10, max_dist=np.inf, viewpoint=None,
+                                regularise=False, eigvals_ptr=None, covs_ptr=None, ids_ptr=None):
+        vp_ = _f32(viewpoint) if viewpoint is not None else None
+        resc = C.c_int64(0)
+        self._check(self._lib.reg_estimate_normals(
+            self._h, C.c_void_p(xyz_ptr), xyz_stride, n, 1, int(k), float(max_dist), _ptr(vp_), 1 if regularise else 0,
+            C.c_void_p(normals_ptr), C.c_void_p(eigvals_ptr) if eigvals_ptr else None,
+            C.c_void_p(covs_ptr) if covs_ptr else None, C.c_void_p(ids_ptr) if ids_ptr else None, C.byref(resc)))
+        return int(resc.value)
 
     # ---- device-pointer entry points (inputs already resident in HBM) ---------------------------
     def set_target_device(self, xyz_ptr, xyz_stride, m, nrm_ptr=None, nrm_stride=3, cov_ptr=None):

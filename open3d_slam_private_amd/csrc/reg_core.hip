@@ -1581,8 +1581,260 @@ __global__ void k_unpermute_f32(const float* __restrict__ in, int64_t n, const u
 }
 
 // =================================================================================================
+// Next row: surface normals / covariances by exact k-NN + PCA on the voxel-bin table
+//   libpointmatcher/pointmatcher/DataPointsFilters/SurfaceNormal.cpp:152-252 (self k-NN incl. the point itself,
+//   mean, C = NN NN^T, eigenvector of the smallest eigenvalue, clamp to [-1,1]);
+//   orientation towards the sensor: open3d_slam/src/CloudRegistration.cpp:37.
+// 16 lanes per point.  Per radius level the group gathers every point of the bin box (within max_dist) into an
+// LDS list, then extracts the k smallest (d2, original index) one by one; the k-th distance <= rho^2 proves the
+// list held every closer point (same exactness argument as the 1-NN search).
+// =================================================================================================
+constexpr int kPcaGroup = 16;
+constexpr int kPcaCap = 512;     // candidates per point and level held in LDS
+constexpr int kPcaMaxK = 32;
+
+// Calls f(j, target point j, d2) on the lanes of one 16-lane group for every target point inside the bin box of
+// level l around p that lies within max_dist.
+template <class F>
+__device__ __forceinline__ void pca_scan_box(const Grid& g, const float3 p, int l, int sub, int gbase, F&& f) {
+    const float rb = g.rho_box[l];
+    const int lox = (int)fminf(fmaxf(bin_coord_f(p.x - rb, g.ox, g.inv_c), 0.f), g.dimx - 1.f);
+    const int loy = (int)fminf(fmaxf(bin_coord_f(p.y - rb, g.oy, g.inv_c), 0.f), g.dimy - 1.f);
+    const int loz = (int)fminf(fmaxf(bin_coord_f(p.z - rb, g.oz, g.inv_c), 0.f), g.dimz - 1.f);
+    const int hix = (int)fminf(fmaxf(bin_coord_f(p.x + rb, g.ox, g.inv_c), 0.f), g.dimx - 1.f);
+    const int hiy = (int)fminf(fmaxf(bin_coord_f(p.y + rb, g.oy, g.inv_c), 0.f), g.dimy - 1.f);
+    const int hiz = (int)fminf(fmaxf(bin_coord_f(p.z + rb, g.oz, g.inv_c), 0.f), g.dimz - 1.f);
+    const int ny = hiy - loy + 1, nz = hiz - loz + 1;
+    const int bx0 = lox >> kBrickLog2;
+    const int nbx = (hix >> kBrickLog2) - bx0 + 1;
+    const int nrow = nbx * ny;
+    const int64_t total = (int64_t)nrow * nz;
+    for (int64_t base = 0; base < total; base += kPcaGroup) {
+        uint32_t s = 0, e = 0;
+        const int64_t t = base + sub;
+        if (t < total) {
+            const int iz = (int)(t / nrow), rem = (int)(t - (int64_t)iz * nrow);
+            const int iy = rem / nbx, ix = rem - iy * nbx;
+            const int bx = bx0 + ix, cy = loy + iy, cz = loz + iz;
+            const int bid = find_brick(g, brick_key((uint32_t)bx, (uint32_t)(cy >> kBrickLog2),
+                                                    (uint32_t)(cz >> kBrickLog2)));
+            if (bid >= 0) {
+                const int x0 = max(lox, bx << kBrickLog2) & (kBrickDim - 1);
+                const int x1 = min(hix, (bx << kBrickLog2) + kBrickDim - 1) & (kBrickDim - 1);
+                const uint32_t* cs = g.cell_start + (size_t)bid * kBrickCells +
+                                     (((cz & (kBrickDim - 1)) << (2 * kBrickLog2)) |
+                                      ((cy & (kBrickDim - 1)) << kBrickLog2));
+                s = cs[x0];
+                e = cs[x1 + 1];
+            }
+        }
+        unsigned mask = (unsigned)((__ballot(e > s) >> gbase) & 0xffffull);
+        while (mask) {
+            const int it = __ffs((int)mask) - 1;
+            mask &= mask - 1;
+            const uint32_t si = (uint32_t)__shfl((int)s, gbase + it);
+            const uint32_t ei = (uint32_t)__shfl((int)e, gbase + it);
+            for (uint32_t j = si + (uint32_t)sub; j < ei; j += kPcaGroup) {
+                const float4 tpt = g.pts[j];
+                const float dx = p.x - tpt.x, dy = p.y - tpt.y, dz = p.z - tpt.z;
+                float a = dx * dx;
+                float b = dy * dy;
+                float d2 = a + b;
+                a = dz * dz;
+                d2 = d2 + a;
+                if (d2 <= g.max_d2) f(j, tpt, d2);
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_knn_pca(Grid g, int64_t n, int k, int start_level, float vx, float vy, float vz, int has_vp, int regularise,
+          float* __restrict__ normals, float* __restrict__ eigvals, float* __restrict__ covs,
+          int32_t* __restrict__ ids_out, uint32_t* __restrict__ n_overflow) {
+    constexpr int GP = 256 / kPcaGroup;   // points per workgroup
+    __shared__ float l_d2[GP][kPcaCap];
+    __shared__ uint32_t l_idx[GP][kPcaCap];
+    __shared__ int l_pos[GP][kPcaCap];
+    __shared__ uint32_t l_cnt[GP];
+    __shared__ int nb_pos[GP][kPcaMaxK];
+    const int grp = threadIdx.x / kPcaGroup, sub = threadIdx.x & (kPcaGroup - 1);
+    const int gbase = (int)(threadIdx.x & 63) & ~(kPcaGroup - 1);
+    const int64_t q = blockIdx.x * (int64_t)GP + grp;
+    if (q >= n) return;   // whole groups leave together; nothing below synchronises across groups
+    const float4 me = g.pts[q];
+    const float3 p = make_float3(me.x, me.y, me.z);
+    const uint32_t my_idx = __float_as_uint(me.w);
+    int m = 0;
+    bool overflow = false;
+    for (int l = min(start_level, g.n_levels - 1); l < g.n_levels; ++l) {
+        if (sub == 0) l_cnt[grp] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        pca_scan_box(g, p, l, sub, gbase, [&](uint32_t j, const float4& tpt, float d2) {
+            const uint32_t slot = atomicAdd(&l_cnt[grp], 1u);
+            if (slot < (uint32_t)kPcaCap) {
+                l_d2[grp][slot] = d2;
+                l_idx[grp][slot] = __float_as_uint(tpt.w);
+                l_pos[grp][slot] = (int)j;
+            }
+        });
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t cnt = l_cnt[grp];
+        const bool listed = cnt <= (uint32_t)kPcaCap;
+        if (!listed) overflow = true;   // too many candidates for LDS: every extraction round rescans the box
+        // extract the k smallest (d2, idx), ascending
+        float last_d2 = -1.f;
+        uint32_t last_idx = 0;
+        m = 0;
+        for (int r = 0; r < k; ++r) {
+            float bd = INFINITY;
+            uint32_t bi = 0xffffffffu;
+            int bp = -1;
+            if (listed) {
+                for (uint32_t t2 = sub; t2 < cnt; t2 += kPcaGroup) {
+                    const float d = l_d2[grp][t2];
+                    const uint32_t ix = l_idx[grp][t2];
+                    const bool after = r == 0 || d > last_d2 || (d == last_d2 && ix > last_idx);
+                    if (after && (d < bd || (d == bd && ix < bi))) {
+                        bd = d;
+                        bi = ix;
+                        bp = l_pos[grp][t2];
+                    }
+                }
+            } else {
+                pca_scan_box(g, p, l, sub, gbase, [&](uint32_t j, const float4& tpt, float d) {
+                    const uint32_t ix = __float_as_uint(tpt.w);
+                    const bool after = r == 0 || d > last_d2 || (d == last_d2 && ix > last_idx);
+                    if (after && (d < bd || (d == bd && ix < bi))) {
+                        bd = d;
+                        bi = ix;
+                        bp = (int)j;
+                    }
+                });
+            }
+#pragma unroll
+            for (int x = 1; x < kPcaGroup; x <<= 1) {
+                const float od = __shfl_xor(bd, x);
+                const uint32_t oi = (uint32_t)__shfl_xor((int)bi, x);
+                const int op = __shfl_xor(bp, x);
+                if (od < bd || (od == bd && oi < bi)) {
+                    bd = od;
+                    bi = oi;
+                    bp = op;
+                }
+            }
+            if (bp < 0) break;
+            if (sub == 0) {
+                nb_pos[grp][r] = bp;
+                if (ids_out) ids_out[(size_t)my_idx * k + r] = (int32_t)bi;
+            }
+            last_d2 = bd;
+            last_idx = bi;
+            ++m;
+        }
+        const float r2 = g.rho[l] * g.rho[l];
+        if ((m == k && last_d2 <= r2) || l == g.n_levels - 1) break;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (sub != 0) return;
+    if (overflow && n_overflow) atomicAdd(n_overflow, 1u);   // statistics only: the result is still exact
+    if (ids_out)
+        for (int r = m; r < k; ++r) ids_out[(size_t)my_idx * k + r] = -1;
+    // PCA: fp32 sequential sums in neighbour order (numeric contract), eigen-decomposition in fp64
+    float mean[3] = {0.f, 0.f, 0.f};
+    for (int r = 0; r < m; ++r) {
+        const float4 t = g.pts[nb_pos[grp][r]];
+        mean[0] = mean[0] + t.x;
+        mean[1] = mean[1] + t.y;
+        mean[2] = mean[2] + t.z;
+    }
+    const float fm = (float)m;
+    if (m > 0) {
+        mean[0] = mean[0] / fm;
+        mean[1] = mean[1] / fm;
+        mean[2] = mean[2] / fm;
+    }
+    float C[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < m; ++r) {
+        const float4 t = g.pts[nb_pos[grp][r]];
+        const float dx = t.x - mean[0], dy = t.y - mean[1], dz = t.z - mean[2];
+        float u;
+        u = dx * dx; C[0] = C[0] + u;
+        u = dx * dy; C[1] = C[1] + u;
+        u = dx * dz; C[2] = C[2] + u;
+        u = dy * dy; C[3] = C[3] + u;
+        u = dy * dz; C[4] = C[4] + u;
+        u = dz * dz; C[5] = C[5] + u;
+    }
+    double M[9] = {C[0], C[1], C[2], C[1], C[3], C[4], C[2], C[4], C[5]}, V[9], lam[3];
+    jacobi_eig_sym(3, M, V, lam);
+    int o0 = 0, o1 = 1, o2 = 2;
+    if (lam[o1] < lam[o0]) { const int t = o0; o0 = o1; o1 = t; }
+    if (lam[o2] < lam[o0]) { const int t = o0; o0 = o2; o2 = t; }
+    if (lam[o2] < lam[o1]) { const int t = o1; o1 = o2; o2 = t; }
+    const double lmax = fabs(lam[o2]);
+    int rank = 0;
+    for (int a = 0; a < 3; ++a)
+        if (lmax > 0 && fabs(lam[a]) > lmax * 3.0 * 1.1920929e-07) ++rank;
+    float nv[3] = {0.f, 0.f, 0.f};
+    if (m >= 3 && rank + 1 >= 3) {
+        const double v[3] = {V[0 * 3 + o0], V[1 * 3 + o0], V[2 * 3 + o0]};
+        double sgn = 1.0;
+        if (has_vp) {
+            const double dot = v[0] * ((double)vx - (double)p.x) + v[1] * ((double)vy - (double)p.y) + v[2] * ((double)vz - (double)p.z);
+            if (dot < 0) sgn = -1.0;
+        } else {
+            int big = 0;
+            if (fabs(v[1]) > fabs(v[big])) big = 1;
+            if (fabs(v[2]) > fabs(v[big])) big = 2;
+            if (v[big] < 0) sgn = -1.0;
+        }
+        for (int a = 0; a < 3; ++a) {
+            const float f = (float)(sgn * v[a]);
+            nv[a] = f > 1.f ? 1.f : (f < -1.f ? -1.f : f);
+        }
+    }
+    const size_t oi = (size_t)my_idx;
+    normals[3 * oi + 0] = nv[0];
+    normals[3 * oi + 1] = nv[1];
+    normals[3 * oi + 2] = nv[2];
+    if (eigvals) {
+        eigvals[3 * oi + 0] = (float)lam[o0];
+        eigvals[3 * oi + 1] = (float)lam[o1];
+        eigvals[3 * oi + 2] = (float)lam[o2];
+    }
+    if (covs) {
+        double Cn[9];
+        if (regularise) {
+            const int oo[3] = {o0, o1, o2};
+            const double w[3] = {1e-3, 1.0, 1.0};
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) {
+                    double t = 0;
+                    for (int e2 = 0; e2 < 3; ++e2) t += w[e2] * V[a * 3 + oo[e2]] * V[b * 3 + oo[e2]];
+                    Cn[3 * a + b] = t;
+                }
+        } else {
+            const double inv = m > 0 ? 1.0 / (double)m : 0.0;
+            const double Cd[9] = {C[0], C[1], C[2], C[1], C[3], C[4], C[2], C[4], C[5]};
+            for (int a = 0; a < 9; ++a) Cn[a] = Cd[a] * inv;
+        }
+        covs[6 * oi + 0] = (float)Cn[0];
+        covs[6 * oi + 1] = (float)Cn[1];
+        covs[6 * oi + 2] = (float)Cn[2];
+        covs[6 * oi + 3] = (float)Cn[4];
+        covs[6 * oi + 4] = (float)Cn[5];
+        covs[6 * oi + 5] = (float)Cn[8];
+    }
+}
+
+// =================================================================================================
 // host side
 // =================================================================================================
+
 
 struct DevBuf {
     void* p = nullptr;
@@ -1613,6 +1865,9 @@ struct reg_handle {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool device_ok = false;   // false: reg_create could not get a HIP device (every entry point then fails loudly)
+    bool structure_only = false;   // workspace handle of reg_estimate_normals: bin table only, no attributes
+    reg_handle* normals_ws = nullptr;
+    DevBuf n_out, n_eig, n_cov, n_ids;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_iter = nullptr;
     bool iter_copy_pending = false;
 
@@ -1756,6 +2011,11 @@ reg_status reg_create(const reg_params* p, reg_handle** out) {
 
 void reg_destroy(reg_handle* h) {
     if (!h) return;
+    if (h->normals_ws) reg_destroy(h->normals_ws);
+    h->n_out.release();
+    h->n_eig.release();
+    h->n_cov.release();
+    h->n_ids.release();
     DevBuf* bufs[] = {&h->t_raw, &h->t_nrm_raw, &h->t_cov_raw, &h->t_centred, &h->t_keys, &h->t_keys2, &h->t_vals,
                       &h->t_vals2, &h->t_pts, &h->t_nrm, &h->t_cov, &h->t_flags, &h->t_scan, &h->t_hash, &h->t_cells,
                       &h->t_tmp, &h->t_misc, &h->s_raw, &h->s_nrm_raw, &h->s_cov_raw, &h->s_xyz, &h->s_nrm, &h->s_cov,
@@ -2004,11 +2264,11 @@ reg_status reg_set_target(reg_handle* h, const float* xyz, int64_t xyz_stride, c
         return REG_EMPTY_TARGET;
     }
     if (!xyz || xyz_stride < 3 || (nrm && nrm_stride < 3) || m > 0x7fffffffLL) return REG_BAD_ARGUMENT;
-    if (h->prm.cost == REG_COST_P2PL && !nrm) {
+    if (h->prm.cost == REG_COST_P2PL && !nrm && !h->structure_only) {
         h->err = "InvalidField: point-to-plane needs the `normals` descriptor on the reference";
         return REG_MISSING_FIELD;
     }
-    if (h->prm.cost == REG_COST_GICP && !cov) {
+    if (h->prm.cost == REG_COST_GICP && !cov && !h->structure_only) {
         h->err = "InvalidField: GICP needs covariances on the reference";
         return REG_MISSING_FIELD;
     }
@@ -2114,6 +2374,85 @@ reg_status reg_set_target(reg_handle* h, const float* xyz, int64_t xyz_stride, c
     h->info.origin[0] = bmin[0];
     h->info.origin[1] = bmin[1];
     h->info.origin[2] = bmin[2];
+    return REG_OK;
+}
+
+reg_status reg_estimate_normals(reg_handle* h, const float* xyz, int64_t xyz_stride, int64_t n, int on_device, int k,
+                                float max_dist, const float* viewpoint, int regularise, float* normals, float* eigvals,
+                                float* covs, int32_t* ids, int64_t* n_rescanned) {
+    if (!h) return REG_BAD_ARGUMENT;
+    if (!h->device_ok) return REG_DEVICE_ERROR;
+    if (!xyz || xyz_stride < 3 || !normals || k < 1 || k > kPcaMaxK || !(max_dist > 0.f) || n > 0x7fffffffLL) {
+        h->err = "reg_estimate_normals: bad argument (1 <= k <= 32, max_dist > 0, normals != NULL)";
+        return REG_BAD_ARGUMENT;
+    }
+    if (n <= 0) {
+        h->err = "The point cloud is empty";
+        return REG_EMPTY_SOURCE;
+    }
+    if (!h->normals_ws) {
+        reg_params p = h->prm;
+        p.cost = REG_COST_GICP;   // no centring: neighbourhoods are formed in the input frame
+        p.disable_halo = 1;
+        reg_handle* w = nullptr;
+        const reg_status cs = reg_create(&p, &w);
+        if (cs != REG_OK) {
+            h->err = std::string("reg_estimate_normals: workspace: ") + reg_last_error(w);
+            reg_destroy(w);
+            return cs;
+        }
+        w->structure_only = true;
+        h->normals_ws = w;
+    }
+    reg_handle* w = h->normals_ws;
+    (void)reg_set_stream(w, h->stream);
+    w->prm.max_dist = max_dist;
+    reg_status st = reg_set_target(w, xyz, xyz_stride, nullptr, 3, nullptr, n, on_device);
+    if (st != REG_OK) {
+        h->err = w->err;
+        return st;
+    }
+    // first radius level expected to hold k neighbours on a surface-like cloud (exactness does not depend on it)
+    const float per = (float)n / (float)std::max<int64_t>(1, w->info.n_cells_occupied);
+    const float need = w->info.cell_size * std::sqrt(1.3f * (float)k / (3.14159265f * std::max(per, 1e-3f)));
+    int start = 0;
+    while (start < w->grid.n_levels - 1 && w->grid.rho[start] < need) ++start;
+    HIPCHK(h, hipSetDevice(h->prm.device));
+    float *d_n = normals, *d_e = eigvals, *d_c = covs;
+    int32_t* d_i = ids;
+    if (!on_device) {
+        HIPCHK(h, h->n_out.reserve((size_t)n * 12));
+        d_n = h->n_out.as<float>();
+        if (eigvals) {
+            HIPCHK(h, h->n_eig.reserve((size_t)n * 12));
+            d_e = h->n_eig.as<float>();
+        }
+        if (covs) {
+            HIPCHK(h, h->n_cov.reserve((size_t)n * 24));
+            d_c = h->n_cov.as<float>();
+        }
+        if (ids) {
+            HIPCHK(h, h->n_ids.reserve((size_t)n * k * 4));
+            d_i = h->n_ids.as<int32_t>();
+        }
+    }
+    HIPCHK(h, w->t_misc.reserve(256));
+    HIPCHK(h, hipMemsetAsync(w->t_misc.p, 0, 4, h->stream));
+    const float vp[3] = {viewpoint ? viewpoint[0] : 0.f, viewpoint ? viewpoint[1] : 0.f, viewpoint ? viewpoint[2] : 0.f};
+    const int64_t blocks = (n + (256 / kPcaGroup) - 1) / (256 / kPcaGroup);
+    k_knn_pca<<<(unsigned)blocks, 256, 0, h->stream>>>(w->grid, n, k, start, vp[0], vp[1], vp[2], viewpoint ? 1 : 0,
+                                                       regularise, d_n, d_e, d_c, d_i, w->t_misc.as<uint32_t>());
+    uint32_t resc = 0;
+    HIPCHK(h, hipMemcpyAsync(&resc, w->t_misc.p, 4, hipMemcpyDeviceToHost, h->stream));
+    if (!on_device) {
+        HIPCHK(h, hipMemcpyAsync(normals, d_n, (size_t)n * 12, hipMemcpyDeviceToHost, h->stream));
+        if (eigvals) HIPCHK(h, hipMemcpyAsync(eigvals, d_e, (size_t)n * 12, hipMemcpyDeviceToHost, h->stream));
+        if (covs) HIPCHK(h, hipMemcpyAsync(covs, d_c, (size_t)n * 24, hipMemcpyDeviceToHost, h->stream));
+        if (ids) HIPCHK(h, hipMemcpyAsync(ids, d_i, (size_t)n * k * 4, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    if (n_rescanned) *n_rescanned = resc;
     return REG_OK;
 }
 

@@ -1024,6 +1024,192 @@ ORC_API int orc_icp_gicp(const float* tgt_xyz, int64_t tgt_stride, const float* 
     return status;
 }
 
+/* ------------------------------------------------------------------------- */
+/* Next row: surface normals / covariances by k-NN PCA           */
+/*   libpointmatcher/pointmatcher/DataPointsFilters/SurfaceNormal.cpp:152-252  */
+/*   (self k-NN incl. the point itself, mean, C = NN*NN^T, smallest eigenvector)*/
+/*   orientation: open3d_slam/src/CloudRegistration.cpp:37 (towards the sensor) */
+/* ------------------------------------------------------------------------- */
+
+typedef struct {
+    float d2;
+    int32_t id;
+} knn_item;
+
+static inline int item_less(float d2a, int32_t ia, float d2b, int32_t ib) { return d2a < d2b || (d2a == d2b && ia < ib); }
+
+/* bounded max-heap on (d2, id) */
+static void heap_push(knn_item* h, int* sz, int k, float d2, int32_t id) {
+    if (*sz < k) {
+        int i = (*sz)++;
+        h[i].d2 = d2;
+        h[i].id = id;
+        while (i > 0) {
+            int p = (i - 1) / 2;
+            if (item_less(h[p].d2, h[p].id, h[i].d2, h[i].id)) {
+                knn_item t = h[p];
+                h[p] = h[i];
+                h[i] = t;
+                i = p;
+            } else
+                break;
+        }
+    } else if (item_less(d2, id, h[0].d2, h[0].id)) {
+        h[0].d2 = d2;
+        h[0].id = id;
+        int i = 0;
+        for (;;) {
+            int l = 2 * i + 1, r = l + 1, m = i;
+            if (l < k && item_less(h[m].d2, h[m].id, h[l].d2, h[l].id)) m = l;
+            if (r < k && item_less(h[m].d2, h[m].id, h[r].d2, h[r].id)) m = r;
+            if (m == i) break;
+            knn_item t = h[m];
+            h[m] = h[i];
+            h[i] = t;
+            i = m;
+        }
+    }
+}
+
+static void kd_search_k(const kd_tree* t, int32_t ni, const float q[3], knn_item* h, int* sz, int k, float max_d2) {
+    const kd_node* nd = &t->nodes[ni];
+    if (nd->dim < 0) {
+        for (int32_t s = nd->left; s < nd->right; ++s) {
+            float d2 = dist2f(q, t->pts + 3 * s);
+            if (d2 <= max_d2) heap_push(h, sz, k, d2, t->idx[s]);
+        }
+        return;
+    }
+    float diff = q[nd->dim] - nd->split;
+    float bound = diff * diff;
+    int32_t nearc = diff <= 0.f ? nd->left : nd->right;
+    int32_t farc = diff <= 0.f ? nd->right : nd->left;
+    kd_search_k(t, nearc, q, h, sz, k, max_d2);
+    float lim = (*sz == k) ? h[0].d2 : max_d2;
+    if (bound <= lim) kd_search_k(t, farc, q, h, sz, k, max_d2);
+}
+
+static int cmp_item(const void* a, const void* b) {
+    const knn_item *x = (const knn_item*)a, *y = (const knn_item*)b;
+    if (x->d2 != y->d2) return x->d2 < y->d2 ? -1 : 1;
+    return (x->id > y->id) - (x->id < y->id);
+}
+
+/* k nearest reference points of every query (self matches allowed), ascending (d2, id); ids -1 / d2 +inf padded */
+ORC_API void orc_knn_k(const void* tree, const float* q_xyz, int64_t stride, int64_t n, int k, float max_dist,
+                       int32_t* ids, float* d2, int n_threads) {
+    const kd_tree* t = (const kd_tree*)tree;
+    const float max_d2 = isinf(max_dist) ? INFINITY : max_dist * max_dist;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 512) num_threads(n_threads > 0 ? n_threads : 1)
+#endif
+    for (int64_t i = 0; i < n; ++i) {
+        knn_item h[64];
+        int sz = 0;
+        if (t->n > 0) kd_search_k(t, 0, q_xyz + i * stride, h, &sz, k, max_d2);
+        qsort(h, (size_t)sz, sizeof(knn_item), cmp_item);
+        for (int j = 0; j < k; ++j) {
+            ids[i * k + j] = j < sz ? h[j].id : -1;
+            d2[i * k + j] = j < sz ? h[j].d2 : INFINITY;
+        }
+    }
+    (void)n_threads;
+}
+
+/* normals (n x 3), eigenvalues ascending (n x 3, may be NULL), covariances 6 unique (n x 6, may be NULL).
+   Numeric contract: mean and C accumulated in fp32 sequentially in neighbour order; eigen-decomposition in fp64. */
+ORC_API void orc_surface_normals(const float* xyz, int64_t stride, int64_t n, int k, float max_dist,
+                                 const float* viewpoint, int regularise, float* normals, float* eigvals, float* covs,
+                                 int32_t* ids_out, int n_threads) {
+    void* tree = orc_kd_build(xyz, stride, n);
+    int32_t* ids = (int32_t*)malloc((size_t)n * k * 4);
+    float* d2 = (float*)malloc((size_t)n * k * 4);
+    orc_knn_k(tree, xyz, stride, n, k, max_dist, ids, d2, n_threads);
+    for (int64_t i = 0; i < n; ++i) {
+        int m = 0;
+        while (m < k && ids[i * k + m] >= 0) ++m;
+        float mean[3] = {0.f, 0.f, 0.f};
+        for (int j = 0; j < m; ++j)
+            for (int a = 0; a < 3; ++a) mean[a] = mean[a] + xyz[(int64_t)ids[i * k + j] * stride + a];
+        for (int a = 0; a < 3; ++a) mean[a] = mean[a] / (float)m;
+        float C[6] = {0, 0, 0, 0, 0, 0}; /* xx xy xz yy yz zz */
+        for (int j = 0; j < m; ++j) {
+            const float* p = xyz + (int64_t)ids[i * k + j] * stride;
+            float dx = p[0] - mean[0], dy = p[1] - mean[1], dz = p[2] - mean[2];
+            float t;
+            t = dx * dx; C[0] = C[0] + t;
+            t = dx * dy; C[1] = C[1] + t;
+            t = dx * dz; C[2] = C[2] + t;
+            t = dy * dy; C[3] = C[3] + t;
+            t = dy * dz; C[4] = C[4] + t;
+            t = dz * dz; C[5] = C[5] + t;
+        }
+        double M[9] = {C[0], C[1], C[2], C[1], C[3], C[4], C[2], C[4], C[5]}, V[9], lam[3];
+        jacobi_eig(3, M, V, lam);
+        /* ascending order */
+        int o[3] = {0, 1, 2};
+        for (int a = 0; a < 3; ++a)
+            for (int b = a + 1; b < 3; ++b)
+                if (lam[o[b]] < lam[o[a]]) {
+                    int t = o[a];
+                    o[a] = o[b];
+                    o[b] = t;
+                }
+        double lmax = fabs(lam[o[2]]);
+        int rank = 0;
+        for (int a = 0; a < 3; ++a)
+            if (fabs(lam[a]) > lmax * 3.0 * 1.1920929e-07 && lmax > 0) ++rank;
+        float nv[3] = {0.f, 0.f, 0.f};
+        if (m >= 3 && rank + 1 >= 3) { /* SurfaceNormal.cpp: C.fullPivHouseholderQr().rank()+1 >= featDim-1 */
+            double v[3] = {V[0 * 3 + o[0]], V[1 * 3 + o[0]], V[2 * 3 + o[0]]};
+            double s = 1.0;
+            if (viewpoint) {
+                double dot = v[0] * ((double)viewpoint[0] - xyz[i * stride]) + v[1] * ((double)viewpoint[1] - xyz[i * stride + 1]) +
+                             v[2] * ((double)viewpoint[2] - xyz[i * stride + 2]);
+                if (dot < 0) s = -1.0;
+            } else {
+                int big = 0;
+                if (fabs(v[1]) > fabs(v[big])) big = 1;
+                if (fabs(v[2]) > fabs(v[big])) big = 2;
+                if (v[big] < 0) s = -1.0;
+            }
+            for (int a = 0; a < 3; ++a) {
+                float f = (float)(s * v[a]);
+                nv[a] = f > 1.f ? 1.f : (f < -1.f ? -1.f : f);
+            }
+        }
+        for (int a = 0; a < 3; ++a) normals[3 * i + a] = nv[a];
+        if (eigvals)
+            for (int a = 0; a < 3; ++a) eigvals[3 * i + a] = (float)lam[o[a]];
+        if (covs) {
+            double Cn[9];
+            if (regularise) { /* plane-like GICP covariance: V diag(1e-3, 1, 1) V^T */
+                const double w[3] = {1e-3, 1.0, 1.0};
+                for (int a = 0; a < 3; ++a)
+                    for (int b = 0; b < 3; ++b) {
+                        double t = 0;
+                        for (int e = 0; e < 3; ++e) t += w[e] * V[a * 3 + o[e]] * V[b * 3 + o[e]];
+                        Cn[3 * a + b] = t;
+                    }
+            } else {
+                const double inv = m > 0 ? 1.0 / m : 0.0;
+                const double Cd[9] = {C[0], C[1], C[2], C[1], C[3], C[4], C[2], C[4], C[5]};
+                for (int a = 0; a < 9; ++a) Cn[a] = Cd[a] * inv;
+            }
+            covs[6 * i + 0] = (float)Cn[0];
+            covs[6 * i + 1] = (float)Cn[1];
+            covs[6 * i + 2] = (float)Cn[2];
+            covs[6 * i + 3] = (float)Cn[4];
+            covs[6 * i + 4] = (float)Cn[5];
+            covs[6 * i + 5] = (float)Cn[8];
+        }
+    }
+    if (ids_out) memcpy(ids_out, ids, (size_t)n * k * 4);
+    free(ids);
+    free(d2);
+    orc_kd_free(tree);
+}
+
 ORC_API int orc_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

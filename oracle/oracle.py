@@ -227,3 +227,27 @@ def icp_gicp(tgt_xyz, tgt_cov, src_xyz, src_cov, T_init=None, *, max_dist=math.i
                        C.c_int(max_iter), C.c_int(fixed_iters), C.c_double(rot_eps), C.c_double(trans_eps),
                        C.c_int(n_threads), _p(T), C.byref(res))
     return T.reshape(4, 4), res
+
+
+def knn_k(tree: "KdTree", q_xyz, k, max_dist=math.inf, n_threads=1):
+    q = _f32(q_xyz)
+    n = q.shape[0]
+    ids = np.empty((n, k), np.int32)
+    d2 = np.empty((n, k), np.float32)
+    lib().orc_knn_k(C.c_void_p(tree.h), _p(q), C.c_int64(q.shape[1]), C.c_int64(n), C.c_int(k), C.c_float(max_dist),
+                    _p(ids), _p(d2), C.c_int(n_threads))
+    return ids, d2
+
+
+def surface_normals(xyz, k, max_dist=math.inf, viewpoint=None, regularise=False, n_threads=1):
+    """(normals n x 3, eigenvalues ascending n x 3, covariances n x 6, neighbour ids n x k)."""
+    x = _f32(xyz)
+    n = x.shape[0]
+    nrm = np.empty((n, 3), np.float32)
+    ev = np.empty((n, 3), np.float32)
+    cov = np.empty((n, 6), np.float32)
+    ids = np.empty((n, k), np.int32)
+    vp = _f32(viewpoint) if viewpoint is not None else None
+    lib().orc_surface_normals(_p(x), C.c_int64(x.shape[1]), C.c_int64(n), C.c_int(k), C.c_float(max_dist), _p(vp),
+                              C.c_int(1 if regularise else 0), _p(nrm), _p(ev), _p(cov), _p(ids), C.c_int(n_threads))
+    return nrm, ev, cov, ids

@@ -132,3 +132,59 @@ def test_gicp_oracle_converges_to_truth():
     T, res = orc.icp_gicp(sc.tgt_xyz, sc.tgt_cov, sc.src_xyz, sc.src_cov, np.eye(4), max_dist=0.5, max_iter=30)
     dt, dr = synth.pose_error(T, sc.T_true)
     assert res.converged == 1 and dt < 5e-3 and dr < 1e-3
+
+
+def test_knn_k_is_exact_and_ordered(car):
+    """orc_knn_k (the k-NN behind the normal-estimation oracle) against brute force, with the distance cut-off,
+    (d2, index) ordering, the point itself as first neighbour and -1 padding."""
+    ref = car[0][:, :3]
+    tree = orc.KdTree(ref)
+    q = ref[:600]
+    k, md = 8, 0.12
+    ids, d2 = orc.knn_k(tree, q, k, md)
+    D = ((q[:, None, :].astype(np.float32) - ref[None, :, :].astype(np.float32)) ** 2)
+    D = (D[..., 0] + D[..., 1]) + D[..., 2]                     # NC3 op order
+    md2 = np.float32(md) * np.float32(md)
+    for i in range(q.shape[0]):
+        order = np.lexsort((np.arange(ref.shape[0]), D[i]))
+        order = order[D[i][order] <= md2][:k]
+        want = np.full(k, -1, np.int32)
+        want[:order.size] = order
+        assert np.array_equal(ids[i], want), i
+        assert np.array_equal(d2[i][:order.size], D[i][order])
+        assert np.all(np.isinf(d2[i][order.size:]))
+        assert ids[i, 0] == i or D[i, ids[i, 0]] == 0.0        # self (or an exact duplicate with a lower index)
+
+
+def test_surface_normals_oracle_against_numpy_and_stored_normals(car):
+    """orc_surface_normals: eigenvector of the smallest eigenvalue of the k-NN scatter matrix (SurfaceNormal.cpp:
+    152-252).  Checked against numpy.linalg.eigh on the same neighbour sets, and -- loosely, the estimator that
+    produced them is unknown -- against the normals stored with the reference's own car_cloud400.csv."""
+    ref = car[0][:, :3]
+    k = 10
+    nrm, ev, cov, ids = orc.surface_normals(ref, k, max_dist=0.5)
+    sel = np.arange(0, ref.shape[0], 37)
+    for i in sel:
+        nb = ref[ids[i][ids[i] >= 0]].astype(np.float64)
+        Cm = np.cov(nb.T, bias=True)
+        w, V = np.linalg.eigh(Cm)
+        assert np.allclose(ev[i] / len(nb), w, rtol=2e-3, atol=1e-7)
+        if w[1] > 4 * max(w[0], 1e-9):                          # well-defined normal
+            assert abs(float(nrm[i] @ V[:, 0])) > 0.999
+        assert np.allclose(cov[i], Cm[np.triu_indices(3)], rtol=2e-3, atol=1e-7)
+        if np.any(nrm[i] != 0):                                  # (degenerate neighbourhoods give the zero vector)
+            assert nrm[i][np.argmax(np.abs(nrm[i]))] > 0        # no viewpoint: largest component positive
+            assert abs(float(np.linalg.norm(nrm[i])) - 1) < 1e-5
+    stored = car[0][:, 3:6]
+    dots = np.abs(np.sum(nrm * stored, axis=1))
+    assert np.median(dots) > 0.95
+    # orientation towards a viewpoint, and the regularised (plane-like) covariance
+    vp = np.array([0.0, 0.0, 50.0], np.float32)
+    n2, _, c2, _ = orc.surface_normals(ref, k, max_dist=0.5, viewpoint=vp, regularise=True)
+    assert np.all(np.sum(n2 * (vp[None] - ref), axis=1) >= 0)
+    C = np.zeros((len(sel), 3, 3))
+    iu = np.triu_indices(3)
+    C[:, iu[0], iu[1]] = c2[sel]
+    C[:, iu[1], iu[0]] = c2[sel]
+    w = np.linalg.eigvalsh(C)
+    assert np.allclose(w, [[1e-3, 1, 1]], rtol=1e-4)
