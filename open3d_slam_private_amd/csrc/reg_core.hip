@@ -1590,7 +1590,7 @@ __global__ void k_unpermute_f32(const float* __restrict__ in, int64_t n, const u
 // list held every closer point (same exactness argument as the 1-NN search).
 // =================================================================================================
 constexpr int kPcaGroup = 16;
-constexpr int kPcaCap = 512;     // candidates per point and level held in LDS
+constexpr int kPcaCap = 256;     // candidates per point and level held in LDS (8 B each)
 constexpr int kPcaMaxK = 32;
 
 // Calls f(j, target point j, d2) on the lanes of one 16-lane group for every target point inside the bin box of
@@ -1649,15 +1649,15 @@ __device__ __forceinline__ void pca_scan_box(const Grid& g, const float3 p, int 
 }
 
 __global__ void __launch_bounds__(256)
-k_knn_pca(Grid g, int64_t n, int k, int start_level, float vx, float vy, float vz, int has_vp, int regularise,
-          float* __restrict__ normals, float* __restrict__ eigvals, float* __restrict__ covs,
-          int32_t* __restrict__ ids_out, uint32_t* __restrict__ n_overflow) {
+k_knn_pca(Grid g, const float* __restrict__ raw_xyz, int64_t raw_stride, int64_t n, int k, int start_level, float vx,
+          float vy, float vz, int has_vp, int regularise, float* __restrict__ normals, float* __restrict__ eigvals,
+          float* __restrict__ covs, int32_t* __restrict__ ids_out, uint32_t* __restrict__ n_overflow) {
     constexpr int GP = 256 / kPcaGroup;   // points per workgroup
     __shared__ float l_d2[GP][kPcaCap];
     __shared__ uint32_t l_idx[GP][kPcaCap];
-    __shared__ int l_pos[GP][kPcaCap];
     __shared__ uint32_t l_cnt[GP];
-    __shared__ int nb_pos[GP][kPcaMaxK];
+    __shared__ uint32_t nb_idx[GP][kPcaMaxK];
+    __shared__ float nb_xyz[GP][kPcaMaxK][3];
     const int grp = threadIdx.x / kPcaGroup, sub = threadIdx.x & (kPcaGroup - 1);
     const int gbase = (int)(threadIdx.x & 63) & ~(kPcaGroup - 1);
     const int64_t q = blockIdx.x * (int64_t)GP + grp;
@@ -1671,12 +1671,11 @@ k_knn_pca(Grid g, int64_t n, int k, int start_level, float vx, float vy, float v
         if (sub == 0) l_cnt[grp] = 0;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
-        pca_scan_box(g, p, l, sub, gbase, [&](uint32_t j, const float4& tpt, float d2) {
+        pca_scan_box(g, p, l, sub, gbase, [&](uint32_t, const float4& tpt, float d2) {
             const uint32_t slot = atomicAdd(&l_cnt[grp], 1u);
             if (slot < (uint32_t)kPcaCap) {
                 l_d2[grp][slot] = d2;
                 l_idx[grp][slot] = __float_as_uint(tpt.w);
-                l_pos[grp][slot] = (int)j;
             }
         });
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -1691,7 +1690,6 @@ k_knn_pca(Grid g, int64_t n, int k, int start_level, float vx, float vy, float v
         for (int r = 0; r < k; ++r) {
             float bd = INFINITY;
             uint32_t bi = 0xffffffffu;
-            int bp = -1;
             if (listed) {
                 for (uint32_t t2 = sub; t2 < cnt; t2 += kPcaGroup) {
                     const float d = l_d2[grp][t2];
@@ -1700,17 +1698,15 @@ k_knn_pca(Grid g, int64_t n, int k, int start_level, float vx, float vy, float v
                     if (after && (d < bd || (d == bd && ix < bi))) {
                         bd = d;
                         bi = ix;
-                        bp = l_pos[grp][t2];
                     }
                 }
             } else {
-                pca_scan_box(g, p, l, sub, gbase, [&](uint32_t j, const float4& tpt, float d) {
+                pca_scan_box(g, p, l, sub, gbase, [&](uint32_t, const float4& tpt, float d) {
                     const uint32_t ix = __float_as_uint(tpt.w);
                     const bool after = r == 0 || d > last_d2 || (d == last_d2 && ix > last_idx);
                     if (after && (d < bd || (d == bd && ix < bi))) {
                         bd = d;
                         bi = ix;
-                        bp = (int)j;
                     }
                 });
             }
@@ -1718,18 +1714,13 @@ k_knn_pca(Grid g, int64_t n, int k, int start_level, float vx, float vy, float v
             for (int x = 1; x < kPcaGroup; x <<= 1) {
                 const float od = __shfl_xor(bd, x);
                 const uint32_t oi = (uint32_t)__shfl_xor((int)bi, x);
-                const int op = __shfl_xor(bp, x);
                 if (od < bd || (od == bd && oi < bi)) {
                     bd = od;
                     bi = oi;
-                    bp = op;
                 }
             }
-            if (bp < 0) break;
-            if (sub == 0) {
-                nb_pos[grp][r] = bp;
-                if (ids_out) ids_out[(size_t)my_idx * k + r] = (int32_t)bi;
-            }
+            if (bi == 0xffffffffu) break;
+            if (sub == 0) nb_idx[grp][r] = bi;
             last_d2 = bd;
             last_idx = bi;
             ++m;
@@ -1739,17 +1730,29 @@ k_knn_pca(Grid g, int64_t n, int k, int start_level, float vx, float vy, float v
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
+    // neighbour coordinates (input frame == table frame: the workspace table is not centred) and ids, in parallel
+    for (int r = sub; r < k; r += kPcaGroup) {
+        if (r < m) {
+            const uint32_t ix = nb_idx[grp][r];
+            const float* s = raw_xyz + (size_t)ix * raw_stride;
+            nb_xyz[grp][r][0] = s[0];
+            nb_xyz[grp][r][1] = s[1];
+            nb_xyz[grp][r][2] = s[2];
+            if (ids_out) ids_out[(size_t)my_idx * k + r] = (int32_t)ix;
+        } else if (ids_out) {
+            ids_out[(size_t)my_idx * k + r] = -1;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
     if (sub != 0) return;
     if (overflow && n_overflow) atomicAdd(n_overflow, 1u);   // statistics only: the result is still exact
-    if (ids_out)
-        for (int r = m; r < k; ++r) ids_out[(size_t)my_idx * k + r] = -1;
     // PCA: fp32 sequential sums in neighbour order (numeric contract), eigen-decomposition in fp64
     float mean[3] = {0.f, 0.f, 0.f};
     for (int r = 0; r < m; ++r) {
-        const float4 t = g.pts[nb_pos[grp][r]];
-        mean[0] = mean[0] + t.x;
-        mean[1] = mean[1] + t.y;
-        mean[2] = mean[2] + t.z;
+        mean[0] = mean[0] + nb_xyz[grp][r][0];
+        mean[1] = mean[1] + nb_xyz[grp][r][1];
+        mean[2] = mean[2] + nb_xyz[grp][r][2];
     }
     const float fm = (float)m;
     if (m > 0) {
@@ -1759,8 +1762,7 @@ k_knn_pca(Grid g, int64_t n, int k, int start_level, float vx, float vy, float v
     }
     float C[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int r = 0; r < m; ++r) {
-        const float4 t = g.pts[nb_pos[grp][r]];
-        const float dx = t.x - mean[0], dy = t.y - mean[1], dz = t.z - mean[2];
+        const float dx = nb_xyz[grp][r][0] - mean[0], dy = nb_xyz[grp][r][1] - mean[1], dz = nb_xyz[grp][r][2] - mean[2];
         float u;
         u = dx * dx; C[0] = C[0] + u;
         u = dx * dy; C[1] = C[1] + u;
@@ -2417,6 +2419,7 @@ reg_status reg_estimate_normals(reg_handle* h, const float* xyz, int64_t xyz_str
     const float need = w->info.cell_size * std::sqrt(1.3f * (float)k / (3.14159265f * std::max(per, 1e-3f)));
     int start = 0;
     while (start < w->grid.n_levels - 1 && w->grid.rho[start] < need) ++start;
+    const float* d_raw = on_device ? xyz : w->t_raw.as<float>();
     HIPCHK(h, hipSetDevice(h->prm.device));
     float *d_n = normals, *d_e = eigvals, *d_c = covs;
     int32_t* d_i = ids;
@@ -2440,7 +2443,7 @@ reg_status reg_estimate_normals(reg_handle* h, const float* xyz, int64_t xyz_str
     HIPCHK(h, hipMemsetAsync(w->t_misc.p, 0, 4, h->stream));
     const float vp[3] = {viewpoint ? viewpoint[0] : 0.f, viewpoint ? viewpoint[1] : 0.f, viewpoint ? viewpoint[2] : 0.f};
     const int64_t blocks = (n + (256 / kPcaGroup) - 1) / (256 / kPcaGroup);
-    k_knn_pca<<<(unsigned)blocks, 256, 0, h->stream>>>(w->grid, n, k, start, vp[0], vp[1], vp[2], viewpoint ? 1 : 0,
+    k_knn_pca<<<(unsigned)blocks, 256, 0, h->stream>>>(w->grid, d_raw, xyz_stride, n, k, start, vp[0], vp[1], vp[2], viewpoint ? 1 : 0,
                                                        regularise, d_n, d_e, d_c, d_i, w->t_misc.as<uint32_t>());
     uint32_t resc = 0;
     HIPCHK(h, hipMemcpyAsync(&resc, w->t_misc.p, 4, hipMemcpyDeviceToHost, h->stream));
