@@ -41,6 +41,20 @@ int main() {
         icp.setShippedChain();
         o3dreg::DataPointsView reference{ref.data(), 4, M, refn.data(), 3};
         o3dreg::DataPointsView reading{rd.data(), 4, N, rdn.data(), 3};
+        // SurfaceNormalDataPointsFilter on the device: the estimated reference normals must agree with the analytic
+        // ones (up to sign) away from the wall/floor edges
+        o3dreg::SurfaceNormalFilter sn;
+        sn.knn = 10;
+        sn.maxDist = 0.5f;
+        std::vector<float> est(3 * (size_t)M);
+        sn.compute(reference, est.data());
+        int agree = 0;
+        for (int i = 0; i < M; ++i) {
+            const float d = est[3 * i] * refn[3 * i] + est[3 * i + 1] * refn[3 * i + 1] + est[3 * i + 2] * refn[3 * i + 2];
+            if (std::fabs(d) > 0.95f) ++agree;
+        }
+        std::printf("estimated normals agree with the analytic ones on %.1f %% of the reference\n", 100.0 * agree / M);
+        if (agree < 0.9 * M) return 4;
         if (!icp.initReference(reference)) return 2;
         const auto T = icp.compute(reading, reference, o3dreg::identity4(), false);
         const auto& r = icp.lastResult();

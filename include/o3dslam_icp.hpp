@@ -119,4 +119,46 @@ private:
     bool matcherIsInitialized_ = false;
 };
 
+// SurfaceNormalDataPointsFilter (DataPointsFilters/SurfaceNormal.cpp:152-252) on the device: exact k-NN (the point
+// itself included) + PCA.  Outputs are written to caller-owned arrays laid out like the `normals` (3 x N),
+// `eigValues` (3 x N, ascending == sortEigen) and `matchedIds` (knn x N) descriptors.
+class SurfaceNormalFilter {
+public:
+    unsigned knn = 5;                                             // SurfaceNormal.h:68
+    float maxDist = std::numeric_limits<float>::infinity();      // SurfaceNormal.h:69
+    bool orientTowardsViewpoint = false;                          // CloudRegistration.cpp:37 (camera location)
+    std::array<float, 3> viewpoint{{0.f, 0.f, 0.f}};
+
+    SurfaceNormalFilter() = default;
+    ~SurfaceNormalFilter() { if (h_) reg_destroy(h_); }
+    SurfaceNormalFilter(const SurfaceNormalFilter&) = delete;
+    SurfaceNormalFilter& operator=(const SurfaceNormalFilter&) = delete;
+
+    void compute(const DataPointsView& cloud, float* normals, float* eigValues = nullptr, int32_t* matchedIds = nullptr,
+                 float* covariances6 = nullptr, bool regularisedCovariances = false) {
+        if (!h_) {
+            reg_params p;
+            reg_default_params(&p);
+            reg_status s = reg_create(&p, &h_);
+            if (s != REG_OK) {
+                std::string msg = h_ ? reg_last_error(h_) : "reg_create failed";
+                if (h_) { reg_destroy(h_); h_ = nullptr; }
+                throw DeviceError(msg);
+            }
+        }
+        if (cloud.getNbPoints() == 0) throw std::runtime_error("The point cloud is empty.");
+        const reg_status s = reg_estimate_normals(h_, cloud.features, cloud.feature_stride, cloud.n,
+                                                  cloud.on_device ? 1 : 0, (int)knn, maxDist,
+                                                  orientTowardsViewpoint ? viewpoint.data() : nullptr,
+                                                  regularisedCovariances ? 1 : 0, normals, eigValues, covariances6,
+                                                  matchedIds, nullptr);
+        if (s == REG_BAD_ARGUMENT) throw InvalidParameter(reg_last_error(h_));
+        if (s == REG_DEVICE_ERROR) throw DeviceError(reg_last_error(h_));
+        if (s != REG_OK) throw std::runtime_error(reg_last_error(h_));
+    }
+
+private:
+    reg_handle* h_ = nullptr;
+};
+
 }  // namespace o3dreg

@@ -7,7 +7,8 @@ but every compute entry point raises if the HIP library or a GPU is missing.
 """
 from .capi import (RegError, RegParams, RegResult, Registration, TargetInfo, default_params, lib_path, load_library,
                    shipped_params)
-from .icp import ICP, DataPoints, RegistrationIcpGeneralized, RegistrationResult
+from .icp import ICP, DataPoints, RegistrationIcpGeneralized, RegistrationResult, SurfaceNormalDataPointsFilter
 
 __all__ = ["RegError", "RegParams", "RegResult", "Registration", "TargetInfo", "default_params", "shipped_params",
-           "lib_path", "load_library", "ICP", "DataPoints", "RegistrationIcpGeneralized", "RegistrationResult"]
+           "lib_path", "load_library", "ICP", "DataPoints", "RegistrationIcpGeneralized", "RegistrationResult",
+           "SurfaceNormalDataPointsFilter"]

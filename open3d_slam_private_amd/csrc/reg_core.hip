@@ -9,6 +9,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstddef>
@@ -265,7 +266,8 @@ struct PrepState {
 };
 // sums: integer centroid sums (NC1); c_override != null: use the given (global, multi-GPU) centroid instead.
 __global__ void k_make_T0(const unsigned long long* __restrict__ sums, int64_t n, float3 c_ref, Xf4 T_init, int centre,
-                          int use_override, float3 c_override, PrepState* __restrict__ out) {
+                          int use_override, float3 c_override, PrepState* __restrict__ out,
+                          PrepState* __restrict__ host_out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     float c[3] = {0.f, 0.f, 0.f};
     if (centre) {
@@ -288,6 +290,11 @@ __global__ void k_make_T0(const unsigned long long* __restrict__ sums, int64_t n
     }
     for (int k = 0; k < 3; ++k) out->c_read[k] = c[k];
     for (int i = 0; i < 16; ++i) out->T0[i] = T0[i];
+    if (host_out) {   // mapped pinned copy for the final composition on the host (a D2H memcpy costs ~50 us of host time)
+        for (int k = 0; k < 3; ++k) host_out->c_read[k] = c[k];
+        for (int i = 0; i < 16; ++i) host_out->T0[i] = T0[i];
+        __threadfence_system();
+    }
 }
 
 // Morton key of the bin the (pre-transformed) reading point falls into: neighbouring lanes then search
@@ -1138,15 +1145,28 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
     __shared__ uint32_t s_cnt, s_csel, s_need_radix;
     __shared__ uint32_t rk_off[65];   // multi-GPU: first global band index of every rank's records (+ total)
     __shared__ uint32_t rk_bad;
-    // read every state field this kernel branches on in ONE batch (each separate use would cost an L2 round trip)
-    const int s_done = it->done, s_stall = it->stall, s_use_trim = it->use_trim;
-    const float s_ratio = it->trim_ratio, s_band_lo = it->band_lo, s_band_hi = it->band_hi;
-    uint32_t s_band_count = it->band_count;
+    // The whole iteration state is staged in LDS by one coalesced load (every separate `it->` access below would
+    // cost an L2 round trip on a single lane); wave 0 writes the modified copy back at the end.  The accumulator
+    // rows do not depend on the state, so their loads are issued in the same batch.
+    constexpr int kStateWords = (int)(sizeof(IterState) / 4);
+    static_assert(sizeof(IterState) % 4 == 0 && kStateWords <= 1024, "IterState must be a whole number of words");
+    __shared__ __attribute__((aligned(16))) uint32_t s_state[kStateWords];
+    IterState* const sit = reinterpret_cast<IterState*>(s_state);
+    const int comp = threadIdx.x & (kSums - 1), part = threadIdx.x / kSums;  // 32 parts x 32 comps
+    if (threadIdx.x < kStateWords) s_state[threadIdx.x] = reinterpret_cast<const uint32_t*>(it)[threadIdx.x];
+    double t = 0;
+    if (!gathered) {
+        const int n_rows = fused ? kAccRows : n_blocks;
+        for (int b = part; b < n_rows; b += 32) t += partials[(size_t)b * kSums + comp];
+    }
+    __syncthreads();
+    const int s_done = sit->done, s_stall = sit->stall, s_use_trim = sit->use_trim;
+    const float s_ratio = sit->trim_ratio, s_band_lo = sit->band_lo, s_band_hi = sit->band_hi;
+    uint32_t s_band_count = sit->band_count;
     bool band_bad = false;   // a band buffer overflowed: the prediction cannot be verified
     if (s_done) return;
     if (fused && s_stall) return;
     const unsigned long long st0 = __builtin_amdgcn_s_memtime();
-    const int comp = threadIdx.x & (kSums - 1), part = threadIdx.x / kSums;  // 32 parts x 32 comps
     if (gathered) {
         // every rank sees the same blocks in the same order -> identical results everywhere, no broadcast needed
         if (threadIdx.x == 0) {
@@ -1191,26 +1211,24 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
             pre[u] = add_comp ? rec(i, comp) : 0.f;
         }
     }
-    double t = 0;
     if (gathered) {
         for (int r = part; r < n_ranks; r += 32)
             t += reinterpret_cast<const double*>(gathered + (size_t)r * kContribFloats)[comp];
     } else if (fused) {
-        for (int b = part; b < kAccRows; b += 32) {
-            t += partials[(size_t)b * kSums + comp];
+        for (int b = part; b < kAccRows; b += 32)
             const_cast<double*>(partials)[(size_t)b * kSums + comp] = 0.0;   // ready for the next iteration
-        }
-    } else {
-        for (int b = part; b < n_blocks; b += 32) t += partials[(size_t)b * kSums + comp];
     }
-    sh[part][comp] = t;
+    // 32 parts -> 1: the two parts of a wave by one shuffle, the 16 waves through LDS (fixed order: deterministic)
+    t += __shfl_xor(t, 32);
+    if ((threadIdx.x & 63) < 32) sh[threadIdx.x >> 6][comp] = t;
     if (threadIdx.x == 0) {
         s_limit = INFINITY;
     }
     lds_barrier();
     if (threadIdx.x < kSums) {
         double s = 0;
-        for (int p = 0; p < 32; ++p) s += sh[p][threadIdx.x];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) s += sh[p][threadIdx.x];
         tot[threadIdx.x] = s;
     }
     lds_barrier();
@@ -1227,7 +1245,7 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
                 it->band_count = 0;
                 host->stall = 1;
                 host->band_count = (int)s_band_count;
-                host->iterations = it->iterations;
+                host->iterations = sit->iterations;
                 host->done = 0;
                 __threadfence_system();
                 __hip_atomic_store(&host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1262,49 +1280,49 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
             }
             lds_barrier();   // LDS-only barrier: the record loads issued above stay in flight
             sx2 = __builtin_amdgcn_s_memtime();
-            if (threadIdx.x < 64) {
-                // wave 0 alone (wave-synchronous, no workgroup barriers): pick the bin, rank inside it
-                const int ln = threadIdx.x;
-                uint32_t loc = 0;
-                for (int j = 0; j < 32; ++j) loc += hist[33 * ln + j];
+            {
+                // block-wide pick (2 bins per thread, padded index): exclusive scan of the 2048 counts
+                const uint32_t b0 = 2u * threadIdx.x, b1 = b0 + 1u;
+                const uint32_t h0 = hist[b0 + (b0 >> 5)], h1 = hist[b1 + (b1 >> 5)];
+                const uint32_t loc = h0 + h1;
                 uint32_t incl = loc;
+                const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
                 for (int o = 1; o < 64; o <<= 1) {
                     const uint32_t v = __shfl_up(incl, o);
                     if (ln >= o) incl += v;
                 }
-                const uint32_t excl = incl - loc;
-                if (loc && rank >= excl && rank < incl) {
-                    uint32_t run = excl;
-                    for (int j = 0; j < 32; ++j) {
-                        const uint32_t hcount = hist[33 * ln + j];
-                        if (hcount && rank >= run && rank < run + hcount) {
-                            pick[0] = 32 * ln + j;
-                            pick[1] = rank - run;
-                            s_csel = hcount;
-                        }
-                        run += hcount;
-                    }
+                if (ln == 63) wave_tot[wv] = incl;
+                lds_barrier();
+                uint32_t base = 0;
+#pragma unroll
+                for (int w = 0; w < 16; ++w) base += (w < wv) ? wave_tot[w] : 0u;
+                const uint32_t excl = base + incl - loc;
+                if (loc && rank >= excl && rank < excl + loc) {   // exactly one thread
+                    const bool first = rank < excl + h0;
+                    pick[0] = first ? b0 : b1;
+                    pick[1] = first ? rank - excl : rank - excl - h0;
+                    s_csel = first ? h0 : h1;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                __builtin_amdgcn_wave_barrier();
+                lds_barrier();
                 const uint32_t bsel = pick[0], rsel = pick[1], csel = s_csel;
                 if (csel <= 64u) {
-                    for (uint32_t i = ln; i < n_band; i += 64) {
+                    // gather the picked bin's values (all threads), rank them directly (wave 0)
+                    for (uint32_t i = threadIdx.x; i < n_band; i += 1024) {
                         const uint32_t key = min((uint32_t)((double)(bd2[i] - u_lo) * kscale), 2047u);
                         if (key == bsel) small[atomicAdd(&s_cnt, 1u)] = bd2[i];
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                    __builtin_amdgcn_wave_barrier();
-                    if ((uint32_t)ln < csel) {
-                        const uint32_t e = small[ln];
+                    lds_barrier();
+                    if (threadIdx.x < csel) {
+                        const uint32_t e = small[threadIdx.x];
                         uint32_t rr = 0;
                         for (uint32_t j = 0; j < csel; ++j) {
                             const uint32_t o = small[j];
-                            rr += (o < e || (o == e && j < (uint32_t)ln)) ? 1u : 0u;
+                            rr += (o < e || (o == e && j < threadIdx.x)) ? 1u : 0u;
                         }
                         if (rr == rsel) s_limit = __uint_as_float(e);
                     }
-                } else if (ln == 0) {
+                } else if (threadIdx.x == 0) {
                     s_need_radix = 1;
                 }
             }
@@ -1353,7 +1371,8 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
                     }
                 }
             }
-            sh[part][comp] = acc;
+            acc += __shfl_xor(acc, 32);
+            if ((threadIdx.x & 63) < 32) sh[threadIdx.x >> 6][comp] = acc;
             if (w_out)
                 for (uint32_t i = threadIdx.x; i < n_band; i += 1024) {
                     if (!(__uint_as_float(bd2[i]) <= limit)) {
@@ -1367,7 +1386,8 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
             __syncthreads();
             if (threadIdx.x < kSums) {
                 double s2 = 0;
-                for (int p = 0; p < 32; ++p) s2 += sh[p][threadIdx.x];
+#pragma unroll
+                for (int p = 0; p < 16; ++p) s2 += sh[p][threadIdx.x];
                 tot[threadIdx.x] += s2;
             }
             __syncthreads();
@@ -1377,12 +1397,12 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
         if (threadIdx.x == 0) s_limit = sel->limit;
         __syncthreads();
     }
-    if (threadIdx.x < kSums) it->sums[threadIdx.x] = tot[threadIdx.x];
+    if (threadIdx.x < kSums) sit->sums[threadIdx.x] = tot[threadIdx.x];
     if (threadIdx.x >= 64) return;   // the rest is wave 0 only (wave-synchronous: no workgroup barriers below)
     const int lane = threadIdx.x;
     const unsigned long long st1 = __builtin_amdgcn_s_memtime();
     unsigned long long st2 = st1, st3 = st1;
-    const bool p2pl = it->cost == REG_COST_P2PL;
+    const bool p2pl = sit->cost == REG_COST_P2PL;
     // ---- R8: 6x6 solve by Gauss-Jordan elimination on the augmented 6x7 system, one entry per lane (fp64).
     // P2PL: A, b are first rounded to fp32 (the reference hands fp32 matrices to its fp64 solver).
     const int r = lane >> 3, c = lane & 7;
@@ -1418,26 +1438,26 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
     if (lane == 0) {
         // band for the next iteration from the limits seen so far
         const float limit = s_limit;
-        it->limit_prev = it->limit_last;
-        it->limit_last = limit;
+        sit->limit_prev = sit->limit_last;
+        sit->limit_last = limit;
         if (!trim || !(limit < INFINITY)) {
-            it->band_lo = INFINITY;   // no trimming / nothing to predict from: every finite match is "certainly kept"
-            it->band_hi = INFINITY;
+            sit->band_lo = INFINITY;   // no trimming / nothing to predict from: every finite match is "certainly kept"
+            sit->band_hi = INFINITY;
         } else {
-            const float prev = it->limit_prev;
+            const float prev = sit->limit_prev;
             float m = 0.3f;
             if (prev < INFINITY && prev > 0.f) m = fminf(fmaxf(2.0f * fabsf(limit - prev) / limit + 0.003f, 0.003f), 0.6f);
-            if (it->debug_narrow_band) m = 1e-7f;   // test hook: forces band mispredictions (stall + repair path)
-            it->band_lo = limit * (1.0f - m);
-            it->band_hi = limit * (1.0f + m);
+            if (sit->debug_narrow_band) m = 1e-7f;   // test hook: forces band mispredictions (stall + repair path)
+            sit->band_lo = limit * (1.0f - m);
+            sit->band_hi = limit * (1.0f + m);
         }
-        mir_w[100] = (uint32_t)it->band_count;
-        it->band_count = 0;
-        it->stall = 0;
-        if (it->update) {
+        mir_w[100] = (uint32_t)sit->band_count;
+        sit->band_count = 0;
+        sit->stall = 0;
+        if (sit->update) {
             if (tot[28] == 0.0) {
-                it->status = REG_NO_CORRESPONDENCES;
-                it->done = 1;
+                sit->status = REG_NO_CORRESPONDENCES;
+                sit->done = 1;
             } else if (p2pl) {
                 float x[6], dT[16], Tn[16];
                 int rank = 6;
@@ -1456,17 +1476,17 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
                     for (int i = 0; i < 6; ++i) b6[i] = -(float)tot[21 + i];
                     rank = solve6_p2pl(H, b6, x);
                 }
-                it->rank_last = rank;
+                sit->rank_last = rank;
                 x_to_T(x, dT);
-                m4_mul(dT, it->T, Tn);  // T_iter = real * T_iter (ICP.cpp:1213-1215)
-                for (int i = 0; i < 16; ++i) it->T[i] = Tn[i];
-                it->iterations += 1;
+                m4_mul(dT, sit->T, Tn);  // T_iter = real * T_iter (ICP.cpp:1213-1215)
+                for (int i = 0; i < 16; ++i) sit->T[i] = Tn[i];
+                sit->iterations += 1;
                 bool iterate;
-                if (it->fixed_iters > 0)
-                    iterate = it->iterations < it->fixed_iters;
+                if (sit->fixed_iters > 0)
+                    iterate = sit->iterations < sit->fixed_iters;
                 else
-                    iterate = it->chk.check(Tn);
-                if (!iterate) it->done = 1;
+                    iterate = sit->chk.check(Tn);
+                if (!iterate) sit->done = 1;
             } else {
                 double dl[6], E[16], Tn[16];
                 int rank = 6;
@@ -1480,30 +1500,30 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
                     for (int i = 0; i < 6; ++i) g[i] = -tot[21 + i];
                     rank = solve_sym6(Hd, g, dl, 1e-12);
                 }
-                it->rank_last = rank;
+                sit->rank_last = rank;
                 se3_exp(dl, E);
                 for (int i = 0; i < 4; ++i)
                     for (int j = 0; j < 4; ++j) {
                         double v = 0;
-                        for (int kk = 0; kk < 4; ++kk) v += it->Td[4 * i + kk] * E[4 * kk + j];
+                        for (int kk = 0; kk < 4; ++kk) v += sit->Td[4 * i + kk] * E[4 * kk + j];
                         Tn[4 * i + j] = v;
                     }
                 for (int i = 0; i < 16; ++i) {
-                    it->Td[i] = Tn[i];
-                    it->T[i] = (float)Tn[i];
+                    sit->Td[i] = Tn[i];
+                    sit->T[i] = (float)Tn[i];
                 }
-                it->iterations += 1;
-                if (it->fixed_iters > 0) {
-                    if (it->iterations >= it->fixed_iters) it->done = 1;
+                sit->iterations += 1;
+                if (sit->fixed_iters > 0) {
+                    if (sit->iterations >= sit->fixed_iters) sit->done = 1;
                 } else {
                     const double dr = sqrt(dl[0] * dl[0] + dl[1] * dl[1] + dl[2] * dl[2]);
                     const double dt = sqrt(dl[3] * dl[3] + dl[4] * dl[4] + dl[5] * dl[5]);
-                    if (dr < (double)it->gicp_rot_eps && dt < (double)it->gicp_trans_eps) {
-                        it->chk.converged = true;
-                        it->done = 1;
-                    } else if (it->iterations >= it->max_iter) {
-                        it->chk.max_iter_reached = true;
-                        it->done = 1;
+                    if (dr < (double)sit->gicp_rot_eps && dt < (double)sit->gicp_trans_eps) {
+                        sit->chk.converged = true;
+                        sit->done = 1;
+                    } else if (sit->iterations >= sit->max_iter) {
+                        sit->chk.max_iter_reached = true;
+                        sit->done = 1;
                     }
                 }
             }
@@ -1511,19 +1531,19 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
         st3 = __builtin_amdgcn_s_memtime();
         // stage the host mirror in LDS (word layout of HostMirror); the whole wave then writes it out
         HostMirror* m = reinterpret_cast<HostMirror*>(mir_w);
-        for (int i = 0; i < 16; ++i) m->T[i] = it->T[i];
-        m->iterations = it->iterations;
-        m->done = it->done;
-        m->status = it->status;
-        m->rank_last = it->rank_last;
-        m->converged = it->chk.converged ? 1 : 0;
-        m->max_iter_reached = it->chk.max_iter_reached ? 1 : 0;
+        for (int i = 0; i < 16; ++i) m->T[i] = sit->T[i];
+        m->iterations = sit->iterations;
+        m->done = sit->done;
+        m->status = sit->status;
+        m->rank_last = sit->rank_last;
+        m->converged = sit->chk.converged ? 1 : 0;
+        m->max_iter_reached = sit->chk.max_iter_reached ? 1 : 0;
         m->stall = 0;
         m->band_count = 0;
-        m->limit_last = it->limit_last;
-        m->limit_prev = it->limit_prev;
-        m->band_lo = it->band_lo;
-        m->band_hi = it->band_hi;
+        m->limit_last = sit->limit_last;
+        m->limit_prev = sit->limit_prev;
+        m->band_lo = sit->band_lo;
+        m->band_hi = sit->band_hi;
         m->pad_nband = (int)mir_w[100];
         m->stamps[0] = st1 - st0;
         m->stamps[1] = st2 - st1;
@@ -1537,6 +1557,8 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
     if (lane < kSums) reinterpret_cast<HostMirror*>(mir_w)->sums[lane] = tot[lane];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // LDS writes of lane 0 visible to the wave
     __builtin_amdgcn_wave_barrier();
+    // write the modified state back (coalesced); the next kernel of the stream reads it from global memory
+    for (int w = lane; w < kStateWords; w += 64) reinterpret_cast<uint32_t*>(it)[w] = s_state[w];
     constexpr int kMirrorWords = (int)(offsetof(HostMirror, seq) / 4);
     uint32_t* hw = reinterpret_cast<uint32_t*>(host);
     for (int w = lane; w < kMirrorWords; w += 64) hw[w] = mir_w[w];
@@ -1900,7 +1922,8 @@ struct reg_handle {
     unsigned long long seq = 0;
     DevBuf t_halo_start, t_halo_cursor, t_halo_pts, i_band, i_acc;
     DevBuf s_prep;
-    PrepState* h_prep = nullptr;      // pinned host copy of the device-side preparation state
+    PrepState* h_prep = nullptr;      // mapped pinned host copy of the device-side preparation state
+    PrepState* d_prep_host = nullptr; // device view of h_prep
     bool prep_pending = false;        // h_prep not yet folded into c_read / T0
     DevBuf i_hint, s_keys, s_keys2, s_perm, s_perm2, s_tmp, i_tmpf;
     const uint32_t* perm = nullptr;   // slot -> input index (null: identity)
@@ -2000,7 +2023,8 @@ reg_status reg_create(const reg_params* p, reg_handle** out) {
     if (hipHostMalloc((void**)&h->h_mirror, sizeof(HostMirror), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&h->d_mirror, h->h_mirror, 0) != hipSuccess ||
         hipHostMalloc((void**)&h->h_iter, sizeof(IterState), hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc((void**)&h->h_prep, sizeof(PrepState), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&h->h_prep, sizeof(PrepState), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&h->d_prep_host, h->h_prep, 0) != hipSuccess ||
         h->i_iter.reserve(sizeof(IterState)) != hipSuccess) {
         h->err = "hipHostMalloc / hipMalloc of the iteration state failed";
         *out = h;
@@ -2553,6 +2577,11 @@ static reg_status prepare_rowmajor(reg_handle* h, const float* T_init_row, const
         h->err = "initial transformation contains non-finite values";
         return REG_BAD_TRANSFORM;
     }
+    const bool ptrace = getenv("O3D_TRACE") != nullptr;
+    const auto pt0 = std::chrono::steady_clock::now();
+    auto pmark = [&](const char* what) {
+        if (ptrace) fprintf(stderr, "[o3dreg] prepare %-18s t=%.1fus\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - pt0).count());
+    };
     HIPCHK(h, hipSetDevice(h->prm.device));
     std::memcpy(h->T_init, T_init_row, 64);
     const int64_t n = h->n;
@@ -2567,6 +2596,7 @@ static reg_status prepare_rowmajor(reg_handle* h, const float* T_init_row, const
         k_centroid_sums<<<blocks, 256, 0, h->stream>>>(h->s_raw.as<float>(), h->s_stride, n,
                                                        h->s_misc.as<unsigned long long>());
     }
+    pmark("centroid");
     Xf4 Ti;
     std::memcpy(Ti.m, T_init_row, 64);
     k_make_T0<<<1, 64, 0, h->stream>>>(h->s_misc.as<unsigned long long>(), n,
@@ -2574,9 +2604,9 @@ static reg_status prepare_rowmajor(reg_handle* h, const float* T_init_row, const
                                        c_override ? 1 : 0,
                                        c_override ? make_float3(c_override[0], c_override[1], c_override[2])
                                                   : make_float3(0.f, 0.f, 0.f),
-                                       h->s_prep.as<PrepState>());
-    HIPCHK(h, hipMemcpyAsync(h->h_prep, h->s_prep.p, sizeof(PrepState), hipMemcpyDeviceToHost, h->stream));
+                                       h->s_prep.as<PrepState>(), h->d_prep_host);
     h->prep_pending = true;
+    pmark("T0+copy");
     const PrepState* ps = h->s_prep.as<PrepState>();
     h->perm = nullptr;
     if (h->prm.sort_source) {
@@ -2591,15 +2621,18 @@ static reg_status prepare_rowmajor(reg_handle* h, const float* T_init_row, const
         k_source_keys<<<grid_for(n), 256, 0, h->stream>>>(h->s_raw.as<float>(), h->s_stride, n, ps, p2pl ? 1 : 0, g.ox, g.oy,
                                                           g.oz, g.inv_c, g.dimx, g.dimy, g.dimz, shift,
                                                           h->s_keys.as<uint32_t>(), h->s_perm.as<uint32_t>());
+        pmark("keys");
         size_t tb = 0;
         HIPCHK(h, rocprim::radix_sort_pairs(nullptr, tb, h->s_keys.as<uint32_t>(), h->s_keys2.as<uint32_t>(),
                                             h->s_perm.as<uint32_t>(), h->s_perm2.as<uint32_t>(), (size_t)n, 0, 21,
                                             h->stream));
+        pmark("sort query");
         HIPCHK(h, h->s_tmp.reserve(tb));
         HIPCHK(h, rocprim::radix_sort_pairs(h->s_tmp.p, tb, h->s_keys.as<uint32_t>(), h->s_keys2.as<uint32_t>(),
                                             h->s_perm.as<uint32_t>(), h->s_perm2.as<uint32_t>(), (size_t)n, 0, 21,
                                             h->stream));
         h->perm = h->s_perm2.as<uint32_t>();
+        pmark("sort");
     }
     k_prepare_source<<<grid_for(n), 256, 0, h->stream>>>(
         h->s_raw.as<float>(), h->s_stride, (p2pl && h->has_snrm) ? h->s_nrm_raw.as<float>() : nullptr, h->s_nstride, n, ps,
@@ -2607,6 +2640,7 @@ static reg_status prepare_rowmajor(reg_handle* h, const float* T_init_row, const
         h->i_hint.as<uint8_t>(), h->i_hist.as<uint32_t>(), h->i_acc.as<double>(), kAccRows * kSums);
     if (!p2pl)
         k_pack_cov<<<grid_for(n), 256, 0, h->stream>>>(h->s_cov_raw.as<float>(), n, h->perm, h->s_cov.as<float4>());
+    pmark("prepare_source");
     HIPCHK(h, hipGetLastError());
     h->prepared = true;
     h->have_match = false;
@@ -2834,10 +2868,11 @@ static void sums_to_system(const double* sums, bool p2pl, float* H, float* b) {
 }
 
 // R10: T = T_refIn_refMean * T_iter * T_refMean_readMean * T_readIn_readMean^-1 (ICP.cpp:1345); GICP: T_iter itself
-static void compose_rowmajor(reg_handle* h, const float* T_iter, float* Tout_row) {
+static void compose_rowmajor(reg_handle* h, const float* T_iter, float* Tout_row, bool later_kernel_reported = false) {
     if (h->prep_pending) {
-        // the D2H copy of PrepState was enqueued in reg_prepare; every caller has synchronised the stream since
-        (void)hipStreamSynchronize(h->stream);
+        // k_make_T0 wrote PrepState into mapped host memory (system-scope fence); it is visible once that kernel has
+        // completed: either a later kernel of the same stream has already reported through the mirror, or wait here
+        if (!later_kernel_reported) (void)hipStreamSynchronize(h->stream);
         std::memcpy(h->c_read, h->h_prep->c_read, 12);
         std::memcpy(h->T0, h->h_prep->T0, 64);
         h->prep_pending = false;
@@ -2911,8 +2946,15 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
     std::memcpy(T_out, T_init, 64);
     float Ti[16];
     col_to_row(T_init, Ti);
+    const auto t_reg0 = std::chrono::steady_clock::now();
+    auto rmark = [&](const char* what) {
+        if (getenv("O3D_TRACE"))
+            fprintf(stderr, "[o3dreg] register %-14s t=%.1fus\n", what,
+                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_reg0).count());
+    };
     reg_status s = prepare_rowmajor(h, Ti);
     if (s != REG_OK) return s;
+    rmark("prepared");
     const bool p2pl = h->prm.cost == REG_COST_P2PL;
     float T_start[16];
     if (p2pl)
@@ -2921,8 +2963,14 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
         std::memcpy(T_start, Ti, 64);
     s = init_iter_state(h, T_start, 1);
     if (s != REG_OK) return s;
+    rmark("iter state");
     h->profiling = h->prm.profile_loop != 0;
-    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    // loop_ms: HIP events only when profiling (record + synchronise cost ~20 us of host time per registration);
+    // otherwise the host clock around the loop -- the loop ends when the last update kernel's mirror has arrived
+    const bool event_timing = h->profiling || getenv("O3D_EVENT_TIMING") != nullptr;
+    if (event_timing) HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    const auto t_loop_begin = std::chrono::steady_clock::now();
+    rmark("ev0");
     const unsigned long long seq0 = h->seq;
     const int fixed = h->prm.fixed_iters;
     const int limit = fixed > 0 ? fixed : h->prm.max_iter;
@@ -2938,6 +2986,7 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
     const bool trace = getenv("O3D_TRACE") != nullptr;
     const float settle_tol = getenv("O3D_SETTLE") ? (float)atof(getenv("O3D_SETTLE")) : 0.05f;
     unsigned long long last_traced = 0;
+    const auto t_loop0 = std::chrono::steady_clock::now();
     unsigned long long acked = seq0;   // every sequence <= acked has either reported or been a no-op
     int stalls = 0;
     for (;;) {
@@ -2969,11 +3018,25 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
                 settled = any && mir->limit_prev < INFINITY && mir->limit_last < INFINITY &&
                           std::fabs(mir->limit_last - mir->limit_prev) <= settle_tol * mir->limit_last;
             }
-            if (!can_fuse || generic_left > 0 || !settled) {
+            const auto tq0 = std::chrono::steady_clock::now();
+            const bool go_generic = !can_fuse || generic_left > 0 || !settled;
+            if (go_generic) {
                 s = enqueue_iteration(h, true);   // weights are always written: reg_get_correspondences reports them
                 if (generic_left > 0) --generic_left;
             } else {
-                s = enqueue_fused(h, true);
+                // Fixed iteration count: nothing the host could learn changes what has to run, so the whole rest of
+                // the registration is submitted in one go (a failed band prediction turns what follows into no-ops
+                // and is repaired above).  Submitting while the device crosses a kernel boundary costs about 6 us per
+                // iteration (measured: rocprofv3 timeline, profiles/), hence no trickle-feeding here.
+                int burst = fixed > 0 && !getenv("O3D_NO_BURST") ? limit - (completed + inflight) : 1;
+                for (; burst > 0 && s == REG_OK; --burst) s = enqueue_fused(h, true);
+            }
+            if (trace) {
+                const auto tq1 = std::chrono::steady_clock::now();
+                fprintf(stderr, "[o3dreg] t=%.1fus enqueue seq %llu (%s) took %.1fus; mirror at %llu\n",
+                        std::chrono::duration<double, std::micro>(tq0 - t_loop0).count(), h->seq - seq0,
+                        go_generic ? "generic" : "fused", std::chrono::duration<double, std::micro>(tq1 - tq0).count(),
+                        std::max(mirror_seq(h), seq0) - seq0);
             }
             if (s != REG_OK) return s;
             continue;
@@ -2987,10 +3050,16 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
         }
     }
     h->last_stalls = stalls;
-    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
-    HIPCHK(h, hipEventSynchronize(h->ev1));
+    rmark("loop done");
+    if (event_timing) {
+        HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+        HIPCHK(h, hipEventSynchronize(h->ev1));
+        (void)hipEventElapsedTime(&res->loop_ms, h->ev0, h->ev1);
+    } else {
+        res->loop_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_loop_begin).count();
+    }
     HIPCHK(h, hipGetLastError());
-    (void)hipEventElapsedTime(&res->loop_ms, h->ev0, h->ev1);
+    rmark("loop timed");
     if (getenv("O3D_STAMPS")) {
         fprintf(stderr, "update kernel stamps (cycles): reduce %llu [rows %llu select %llu band-add %llu] solve %llu update+check %llu mirror %llu\n", mir->stamps[0],
                 mir->stamps[4], mir->stamps[5], mir->stamps[6], mir->stamps[1], mir->stamps[2], mir->stamps[3]);
@@ -3022,10 +3091,11 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
     }
     float T_iter[16], Tout_row[16];
     std::memcpy(T_iter, mir->T, 64);
-    compose_rowmajor(h, T_iter, Tout_row);
+    compose_rowmajor(h, T_iter, Tout_row, /*later_kernel_reported=*/true);
     row_to_col(T_iter, res->T_iter_last);
     row_to_col(Tout_row, T_out);
     res->n_band_stalls = h->last_stalls;
+    rmark("return");
     return REG_OK;
 }
 

@@ -191,6 +191,38 @@ class ICP:
 
 
 @dataclass
+class SurfaceNormalDataPointsFilter:
+    """SurfaceNormalDataPointsFilter (DataPointsFilters/SurfaceNormal.h:68-78, SurfaceNormal.cpp:152-252) on the
+    device: parameters by the reference's names; `epsilon` must be 0 (the search is exact).  `filter` returns a
+    DataPoints with the `normals` descriptor added (keepNormals) and keeps `eigValues` / `matchedIds` on the filter."""
+
+    def __init__(self, knn=5, maxDist=float("inf"), epsilon=0.0, keepNormals=True, keepEigenValues=False,
+                 keepMatchedIds=False, viewpoint=None):
+        if knn < 3:
+            raise InvalidParameter("knn: minimum 3 (SurfaceNormal.h:68)")
+        if knn > 32:
+            raise InvalidParameter("knn: this build supports at most 32 neighbours")
+        if epsilon != 0.0:
+            raise InvalidParameter("epsilon: only the exact search (0) is implemented")
+        if not (maxDist > 0):
+            raise InvalidParameter("maxDist: must be > 0")
+        self.knn, self.maxDist, self.keepNormals = int(knn), float(maxDist), keepNormals
+        self.keepEigenValues, self.keepMatchedIds, self.viewpoint = keepEigenValues, keepMatchedIds, viewpoint
+        self.eigValues = self.matchedIds = None
+        self._reg = None
+
+    def filter(self, cloud: DataPoints) -> DataPoints:
+        if self._reg is None:
+            self._reg = capi.Registration(capi.default_params())
+        try:
+            out = self._reg.estimate_normals(cloud.features, k=self.knn, max_dist=self.maxDist, viewpoint=self.viewpoint,
+                                             want_eigvals=self.keepEigenValues, want_ids=self.keepMatchedIds)
+        except RegError as e:
+            raise _translate(e) from None
+        self.eigValues, self.matchedIds = out.get("eigvals"), out.get("ids")
+        return DataPoints(cloud.features, out["normals"] if self.keepNormals else cloud.normals, cloud.covariances)
+
+
 class RegistrationResult:
     """open3d::pipelines::registration::RegistrationResult fields consumed by the reference
     (Odometry.cpp:56,77, PlaceRecognition.cpp:118)."""

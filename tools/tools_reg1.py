@@ -1,11 +1,17 @@
-import sys, numpy as np
 import os, sys
+import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from open3d_slam_private_amd import capi, synth
 n_src, n_tgt = int(sys.argv[1]), int(sys.argv[2])
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 sc = synth.make_scene(n_src, n_tgt, seed=1236)
 p = capi.shipped_params(); p.fixed_iters = 20
 reg = capi.Registration(p)
 reg.set_target(sc.tgt_xyz, sc.tgt_nrm); reg.set_source(sc.src_xyz, sc.src_nrm)
-T, res = reg.register(np.eye(4))
-print("loop_ms", res.loop_ms, "stalls", res.n_band_stalls, "iters", res.iterations)
+ms = []
+for r in range(reps):
+    if r == reps - 1 and os.environ.get('TRACE_LAST'):
+        os.environ['O3D_TRACE'] = '1'
+    T, res = reg.register(np.eye(4))
+    ms.append(res.loop_ms)
+print("loop_ms", " ".join(f"{m:.3f}" for m in ms), "stalls", res.n_band_stalls, "iters", res.iterations)
