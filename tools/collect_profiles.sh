@@ -11,4 +11,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OU
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $CMD > $OUT/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $CMD > $OUT/bench_write.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/calib_fetch -- ./tools/tools_calib > $OUT/calib.log 2>&1
+# next-row kernel (normals / covariances): kernel trace + stats of 1 M points, k = 10
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/normals -- python tools/tools_normals.py 1000000 10 > $OUT/normals.log 2>&1
+# timeline of one warm registration (gaps between kernels)
+rocprofv3 --kernel-trace --output-format csv -d $OUT/timeline -- python tools/tools_reg1.py 100000 1000000 4 > $OUT/timeline_run.log 2>&1
+python tools/tools_timeline.py $OUT/timeline > $OUT/timeline.txt
 python tools/summarise_profiles.py $OUT

@@ -1,6 +1,13 @@
 #!/usr/bin/env python3
 """Turns the rocprofv3 CSVs collected by tools/collect_profiles.sh into the small tracked files under profiles/."""
-import collections, csv, glob, json, os, shutil, sys
+import collections, csv, glob as _glob, json, os, shutil, sys
+
+
+class glob:  # newest first: gpurun merges new runs next to older ones
+    @staticmethod
+    def glob(p):
+        return sorted(_glob.glob(p), key=os.path.getmtime, reverse=True)
+
 
 out = sys.argv[1]
 dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
@@ -56,4 +63,19 @@ with open(os.path.join(dst, "r01_bench_c2_trace_summary.txt"), "w") as fh:
 for line in open(os.path.join(out, "bench_trace.log")):
     if line.startswith('{"metric"'):
         open(os.path.join(dst, "r01_bench_c2_line.json"), "w").write(line)
+nst = glob.glob(os.path.join(out, "normals", "*", "*kernel_stats.csv"))
+if nst:
+    rows = list(csv.DictReader(open(nst[0])))
+    with open(os.path.join(dst, "r01_normals_1M_k10_kernel_stats.csv"), "w", newline="") as fh:
+        w = csv.DictWriter(fh, fieldnames=rows[0].keys())
+        w.writeheader()
+        for r in rows:
+            r["Name"] = r["Name"][:100]
+            w.writerow(r)
+    for line in open(os.path.join(out, "normals.log")):
+        if line.startswith(("GPU", "CPU")):
+            open(os.path.join(dst, "r01_normals_1M_k10_line.txt"), "a").write(line)
+tl = os.path.join(out, "timeline.txt")
+if os.path.exists(tl):
+    shutil.copy(tl, os.path.join(dst, "r01_registration_timeline.txt"))
 print(json.dumps(summary, indent=1))

@@ -6,6 +6,7 @@ n_src, n_tgt = int(sys.argv[1]), int(sys.argv[2])
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 sc = synth.make_scene(n_src, n_tgt, seed=1236)
 p = capi.shipped_params(); p.fixed_iters = 20
+if os.environ.get('CELL'): p.cell_size = float(os.environ['CELL'])
 reg = capi.Registration(p)
 reg.set_target(sc.tgt_xyz, sc.tgt_nrm); reg.set_source(sc.src_xyz, sc.src_nrm)
 ms = []
