@@ -202,7 +202,8 @@ __global__ void k_brick_heads(const uint64_t* __restrict__ keys, int64_t n, uint
 // brick_id = inclusive_scan(flags) - 1.  Inserts brick heads into the hash and counts points per bin.
 __global__ void k_fill_tables(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ flags,
                               const uint32_t* __restrict__ scan, int64_t n, HashEntry* hash, uint32_t mask,
-                              uint32_t* __restrict__ counts, uint32_t* __restrict__ occupied) {
+                              uint32_t* __restrict__ counts, uint32_t* __restrict__ occupied,
+                              int32_t* __restrict__ dir, int bdx, int bdy) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t bid = scan[i] - 1u;
@@ -219,6 +220,12 @@ __global__ void k_fill_tables(const uint64_t* __restrict__ keys, const uint32_t*
                 break;
             }
             h = (h + 1) & mask;
+        }
+        if (dir) {
+            const uint32_t m18 = (1u << kBrickBits) - 1u;
+            const uint32_t bx = (uint32_t)bk & m18, by = (uint32_t)(bk >> kBrickBits) & m18,
+                           bz = (uint32_t)(bk >> (2 * kBrickBits)) & m18;
+            dir[((size_t)bz * bdy + by) * bdx + bx] = (int32_t)bid;
         }
     }
     const uint32_t old = atomicAdd(&counts[(size_t)bid * kBrickCells + local], 1u);
@@ -414,6 +421,10 @@ k_match(const float4* __restrict__ src, int64_t n, const IterState* __restrict__
     }
 }
 
+// LDS words per group for the wide level scan (segment starts + exclusive offsets + sentinel)
+template <int G>
+constexpr int kSegWords = 2 * G * kSegPerLane + 2;
+
 // Cooperative variant: G (8 or 4) lanes per reading point (256/G points per 256-thread workgroup).
 // `hint` (one byte per point, may be null) carries the terminating level of the previous iteration.
 template <int G>
@@ -422,6 +433,7 @@ k_match_g8(const float4* __restrict__ src, int64_t n, const IterState* __restric
            float* __restrict__ d2, uint32_t* __restrict__ hist0 /* 2048 or null */,
            uint32_t* __restrict__ hist2_to_zero, uint8_t* __restrict__ hint, int shift0, int debug, int n_blocks) {
     __shared__ uint32_t sh[2048];
+    __shared__ uint32_t seg_lds[(256 / G) * kSegWords<G>];
     if (it->done) return;
     const Xf T = load_xf(it);
     if (hist2_to_zero && blockIdx.x == 0)
@@ -449,7 +461,7 @@ k_match_g8(const float4* __restrict__ src, int64_t n, const IterState* __restric
         const int hv = hint ? (int)hint[q] : 0;
         const int first = hv >= 2 ? hv - 2 : -1;
         int lvl;
-        const Best b = nearest_group<G>(g, p, sub, first, &lvl);
+        const Best b = nearest_group<G>(g, p, sub, first, &lvl, seg_lds + (threadIdx.x / G) * kSegWords<G>);
         if (sub == 0) {
             pos[q] = b.pos;
             d2[q] = b.pos >= 0 ? b.d2 : INFINITY;
@@ -966,6 +978,7 @@ k_iter_fused(const float4* __restrict__ src, const float4* __restrict__ src_nrm,
              float* __restrict__ band, int band_cap, double* __restrict__ partials, int n_blocks) {
     constexpr int CP = kSums / G;   // components owned by each lane of a group
     __shared__ double sh[4][kSums];
+    __shared__ uint32_t seg_lds[(256 / G) * kSegWords<G>];
     if (it->done || it->stall) return;
     const Xf T = load_xf(it);
     const float band_lo = it->band_lo, band_hi = it->band_hi;
@@ -981,7 +994,8 @@ k_iter_fused(const float4* __restrict__ src, const float4* __restrict__ src_nrm,
         const float3 p = xf_point(T, s.x, s.y, s.z);
         const int hv = hint ? (int)hint[q] : 0;
         int lvl;
-        const Best b = nearest_group<G>(g, p, sub, hv >= 2 ? hv - 2 : -1, &lvl);
+        const Best b = nearest_group<G>(g, p, sub, hv >= 2 ? hv - 2 : -1, &lvl,
+                                        seg_lds + (threadIdx.x / G) * kSegWords<G>);
         float vals[kSums];
 #pragma unroll
         for (int k = 0; k < kSums; ++k) vals[k] = 0.f;
@@ -1638,8 +1652,7 @@ __device__ __forceinline__ void pca_scan_box(const Grid& g, const float3 p, int 
             const int iz = (int)(t / nrow), rem = (int)(t - (int64_t)iz * nrow);
             const int iy = rem / nbx, ix = rem - iy * nbx;
             const int bx = bx0 + ix, cy = loy + iy, cz = loz + iz;
-            const int bid = find_brick(g, brick_key((uint32_t)bx, (uint32_t)(cy >> kBrickLog2),
-                                                    (uint32_t)(cz >> kBrickLog2)));
+            const int bid = brick_lookup(g, bx, cy >> kBrickLog2, cz >> kBrickLog2);
             if (bid >= 0) {
                 const int x0 = max(lox, bx << kBrickLog2) & (kBrickDim - 1);
                 const int x1 = min(hix, (bx << kBrickLog2) + kBrickDim - 1) & (kBrickDim - 1);
@@ -1900,7 +1913,7 @@ struct reg_handle {
     bool has_tnrm = false, has_tcov = false;
     float c_ref[3] = {0, 0, 0};
     DevBuf t_raw, t_nrm_raw, t_cov_raw, t_centred, t_keys, t_keys2, t_vals, t_vals2, t_pts, t_nrm, t_cov, t_flags,
-        t_scan, t_hash, t_cells, t_tmp, t_misc;
+        t_scan, t_hash, t_cells, t_tmp, t_misc, t_dir;
     Grid grid;
     reg_target_info info;
     float target_build_ms = 0.f;
@@ -2044,7 +2057,7 @@ void reg_destroy(reg_handle* h) {
     h->n_ids.release();
     DevBuf* bufs[] = {&h->t_raw, &h->t_nrm_raw, &h->t_cov_raw, &h->t_centred, &h->t_keys, &h->t_keys2, &h->t_vals,
                       &h->t_vals2, &h->t_pts, &h->t_nrm, &h->t_cov, &h->t_flags, &h->t_scan, &h->t_hash, &h->t_cells,
-                      &h->t_tmp, &h->t_misc, &h->s_raw, &h->s_nrm_raw, &h->s_cov_raw, &h->s_xyz, &h->s_nrm, &h->s_cov,
+                      &h->t_tmp, &h->t_misc, &h->t_dir, &h->s_raw, &h->s_nrm_raw, &h->s_cov_raw, &h->s_xyz, &h->s_nrm, &h->s_cov,
                       &h->s_misc, &h->i_pos, &h->i_d2, &h->i_w, &h->i_hist, &h->i_state, &h->i_partials, &h->i_sums,
                       &h->i_ids, &h->d_contrib, &h->d_gathered, &h->s_prep, &h->i_iter, &h->t_halo_start, &h->t_halo_cursor, &h->t_halo_pts, &h->i_band, &h->i_acc, &h->i_hint, &h->s_keys, &h->s_keys2, &h->s_perm, &h->s_perm2, &h->s_tmp, &h->i_tmpf};
     for (DevBuf* b : bufs) b->release();
@@ -2168,9 +2181,25 @@ static reg_status build_grid(reg_handle* h, float c, const float bmin[3], const 
     HIPCHK(h, hipMemsetAsync(h->t_cells.p, 0, n_cells * 4, h->stream));
     HIPCHK(h, h->t_misc.reserve(256));
     HIPCHK(h, hipMemsetAsync(h->t_misc.p, 0, 64, h->stream));
+    // dense brick directory (brick id per brick coordinate) when the brick grid is small enough: one 4-byte load
+    // instead of a 64-bit hash + probe per row segment
+    const int bdx = (int)std::ceil(dims[0] / kBrickDim), bdy = (int)std::ceil(dims[1] / kBrickDim),
+              bdz = (int)std::ceil(dims[2] / kBrickDim);
+    const size_t n_dir = (size_t)bdx * bdy * bdz;
+    const bool use_dir = n_dir <= ((size_t)64 << 20) && !(h->prm.debug_flags & 32);
+    if (use_dir) {
+        HIPCHK(h, h->t_dir.reserve(n_dir * 4));
+        HIPCHK(h, hipMemsetAsync(h->t_dir.p, 0xff, n_dir * 4, h->stream));
+    }
     k_fill_tables<<<grid_for(m), 256, 0, h->stream>>>(h->t_keys2.as<uint64_t>(), h->t_flags.as<uint32_t>(),
                                                        h->t_scan.as<uint32_t>(), m, h->t_hash.as<HashEntry>(), cap - 1,
-                                                       h->t_cells.as<uint32_t>(), h->t_misc.as<uint32_t>());
+                                                       h->t_cells.as<uint32_t>(), h->t_misc.as<uint32_t>(),
+                                                       use_dir ? h->t_dir.as<int32_t>() : nullptr, bdx, bdy);
+    g.brick_dir = use_dir ? h->t_dir.as<int32_t>() : nullptr;
+    g.bdx = bdx;
+    g.bdy = bdy;
+    g.bdz = bdz;
+    g.wide_scan = (h->prm.debug_flags & 16) ? 0 : 1;
     size_t ex_bytes = 0;
     HIPCHK(h, rocprim::exclusive_scan(nullptr, ex_bytes, h->t_cells.as<uint32_t>(), h->t_cells.as<uint32_t>(), 0u,
                                       n_cells, rocprim::plus<uint32_t>(), h->stream));
@@ -2184,7 +2213,7 @@ static reg_status build_grid(reg_handle* h, float c, const float bmin[3], const 
     g.cell_start = h->t_cells.as<uint32_t>();
     h->info.n_bricks = nb;
     h->info.n_cells_occupied = *occupied;
-    h->info.table_bytes = (int64_t)((size_t)cap * sizeof(HashEntry) + n_cells * 4);
+    h->info.table_bytes = (int64_t)((size_t)cap * sizeof(HashEntry) + n_cells * 4 + (use_dir ? n_dir * 4 : 0));
     h->info.cell_size = c;
     return REG_OK;
 }

@@ -52,6 +52,11 @@ struct Grid {
     const float4* halo_pts;
     float rho_h;                 // exactness radius of the halo level
     int level_after_halo;        // first regular level with rho > rho_h
+    // Dense brick directory (brick id or -1 per brick coordinate): replaces the hash probe when the brick grid is
+    // small enough to be stored densely (null otherwise).
+    const int32_t* brick_dir;
+    int bdx, bdy, bdz;
+    int wide_scan;               // 1: levels are scanned with 4 row segments per lane in flight (nearest_group)
 };
 
 struct Xf {  // row-major 3x4
@@ -103,6 +108,12 @@ __device__ __forceinline__ int find_brick(const Grid& g, uint64_t bk) {
         if (e.key == kEmptyKey) return -1;
         h = (h + 1) & g.hash_mask;
     }
+}
+
+// brick id of brick coordinate (bx, by, bz) (inside the grid), or -1
+__device__ __forceinline__ int brick_lookup(const Grid& g, int bx, int by, int bz) {
+    if (g.brick_dir) return g.brick_dir[((size_t)bz * g.bdy + by) * g.bdx + bx];
+    return find_brick(g, brick_key((uint32_t)bx, (uint32_t)by, (uint32_t)bz));
 }
 
 struct Best {
@@ -283,6 +294,114 @@ __device__ __forceinline__ Best group_min_lazy(const Grid& g, Best b, int gbase)
     return r;
 }
 
+// Wide level scan: the same bin box as below, but every lane looks up kSegPerLane row segments at once (the brick
+// directory loads, then the bin-start loads, are all in flight together) and the group scans the concatenation of up
+// to G * kSegPerLane segments in one flattened pass.  The compacted segment list {first point, exclusive offset}
+// lives in LDS (`seg`: 2 * G * kSegPerLane + 2 words owned by this group); each lane walks it monotonically.
+// Large radii (first iterations of a registration) are bound by dependent-load rounds: this cuts them roughly in half.
+constexpr int kSegPerLane = 4;
+
+template <int G>
+__device__ __forceinline__ void scan_level_wide(const Grid& g, const float3 p, int sub, int gbase, int l,
+                                                uint32_t* seg, Best& best) {
+    constexpr int S = kSegPerLane, CAP = G * S;
+    uint32_t* const seg_st = seg;         // [CAP]
+    uint32_t* const seg_ex = seg + CAP;   // [CAP + 1]
+    const float rb = g.rho_box[l];
+    const int lox = (int)fminf(fmaxf(bin_coord_f(p.x - rb, g.ox, g.inv_c), 0.f), g.dimx - 1.f);
+    const int loy = (int)fminf(fmaxf(bin_coord_f(p.y - rb, g.oy, g.inv_c), 0.f), g.dimy - 1.f);
+    const int loz = (int)fminf(fmaxf(bin_coord_f(p.z - rb, g.oz, g.inv_c), 0.f), g.dimz - 1.f);
+    const int hix = (int)fminf(fmaxf(bin_coord_f(p.x + rb, g.ox, g.inv_c), 0.f), g.dimx - 1.f);
+    const int hiy = (int)fminf(fmaxf(bin_coord_f(p.y + rb, g.oy, g.inv_c), 0.f), g.dimy - 1.f);
+    const int hiz = (int)fminf(fmaxf(bin_coord_f(p.z + rb, g.oz, g.inv_c), 0.f), g.dimz - 1.f);
+    const int ny = hiy - loy + 1, nz = hiz - loz + 1;
+    const int bx0 = lox >> kBrickLog2;
+    const int nbx = (hix >> kBrickLog2) - bx0 + 1;
+    const int nrow = nbx * ny;
+    const int total = nrow * nz;
+    const unsigned gmask = (1u << G) - 1u;
+    for (int base = 0; base < total; base += CAP) {
+        // phase 1a: brick ids of this lane's segments (independent loads)
+        int bid[S], off[S];
+#pragma unroll
+        for (int u = 0; u < S; ++u) {
+            const int t = base + u * G + sub;
+            bid[u] = -1;
+            off[u] = 0;
+            if (t < total) {
+                const int iz = t / nrow, rem = t - iz * nrow;
+                const int iy = rem / nbx, ix = rem - iy * nbx;
+                const int bx = bx0 + ix, cy = loy + iy, cz = loz + iz;
+                bid[u] = brick_lookup(g, bx, cy >> kBrickLog2, cz >> kBrickLog2);
+                const int x0 = max(lox, bx << kBrickLog2) & (kBrickDim - 1);
+                const int x1 = min(hix, (bx << kBrickLog2) + kBrickDim - 1) & (kBrickDim - 1);
+                off[u] = (((cz & (kBrickDim - 1)) << (2 * kBrickLog2)) | ((cy & (kBrickDim - 1)) << kBrickLog2)) |
+                         (x0 << 12) | (x1 << 16);
+            }
+        }
+        // phase 1b: bin starts (independent loads)
+        uint32_t s[S], e[S];
+#pragma unroll
+        for (int u = 0; u < S; ++u) {
+            s[u] = 0;
+            e[u] = 0;
+            if (bid[u] >= 0) {
+                const uint32_t* cs = g.cell_start + (size_t)bid[u] * kBrickCells + (off[u] & 0xfff);
+                s[u] = cs[(off[u] >> 12) & 15];
+                e[u] = cs[((off[u] >> 16) & 15) + 1];
+            }
+        }
+        // compact the non-empty segments into the group's LDS list, in segment order
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t run_pts = 0, run_seg = 0;
+#pragma unroll
+        for (int u = 0; u < S; ++u) {
+            const uint32_t cnt = e[u] - s[u];
+            uint32_t incl = cnt;
+#pragma unroll
+            for (int o = 1; o < G; o <<= 1) {
+                const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
+                if (sub >= o) incl += v;
+            }
+            const uint32_t tot_u = (uint32_t)__shfl((int)incl, gbase + G - 1);
+            const unsigned m = (unsigned)(__ballot(cnt != 0) >> gbase) & gmask;
+            if (cnt != 0) {
+                const uint32_t my = run_seg + (uint32_t)__popc(m & ((1u << sub) - 1u));
+                seg_st[my] = s[u];
+                seg_ex[my] = run_pts + incl - cnt;
+            }
+            run_pts += tot_u;
+            run_seg += (uint32_t)__popc(m);
+        }
+        if (run_pts == 0) continue;
+        if (sub == 0) seg_ex[run_seg] = run_pts;   // sentinel: end of the last segment
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        // phase 2: flattened scan, 4 independent 16-byte loads in flight per lane
+        uint32_t k = 0, cur_ex = 0, cur_st = seg_st[0], next_ex = seg_ex[1];
+        constexpr int kUnroll = 4;
+        for (uint32_t f0 = 0; f0 < run_pts; f0 += kUnroll * G) {
+            float4 tv[kUnroll];
+            uint32_t jv[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                const uint32_t f = min(f0 + (uint32_t)(u * G + sub), run_pts - 1);   // clamp: duplicates are harmless
+                while (f >= next_ex) {
+                    ++k;
+                    cur_ex = next_ex;
+                    cur_st = seg_st[k];
+                    next_ex = seg_ex[k + 1];
+                }
+                jv[u] = cur_st + (f - cur_ex);
+                tv[u] = g.pts[jv[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) consider(g, p, tv[u], (int)jv[u], best);
+        }
+    }
+}
+
 // `sub` = lane index inside the group (0..7); `first_level` lets the caller skip radii that were too
 // small for this query in the previous iteration (any starting level is exact).  Returns the level at
 // which the search terminated through *level_out.
@@ -292,7 +411,8 @@ __device__ __forceinline__ Best group_min_lazy(const Grid& g, Best b, int gbase)
 // group scans every non-empty segment TOGETHER, lane k reading point s+k, s+k+8, ... -- consecutive
 // 16-byte records, i.e. one or two cache lines per group step instead of one line per lane.
 template <int G>
-__device__ __forceinline__ Best nearest_group(const Grid& g, float3 p, int sub, int first_level, int* level_out) {
+__device__ __forceinline__ Best nearest_group(const Grid& g, float3 p, int sub, int first_level, int* level_out,
+                                              uint32_t* seg = nullptr) {
     Best best;
     best.d2 = INFINITY;
     best.idx = 0xffffffffu;
@@ -330,6 +450,20 @@ __device__ __forceinline__ Best nearest_group(const Grid& g, float3 p, int sub, 
     }
     l = max(l, 0);
     for (; l < g.n_levels; ++l) {
+        if (seg && g.wide_scan) {
+            scan_level_wide<G>(g, p, sub, gbase, l, seg, best);
+            best = group_min<G>(best);
+            const float rw = g.rho[l];
+            if (best.pos >= 0 && best.d2 <= rw * rw) break;
+            if (best.pos >= 0) {
+                while (l + 2 < g.n_levels) {
+                    const float rn = g.rho[l + 1];
+                    if (rn * rn >= best.d2) break;
+                    ++l;
+                }
+            }
+            continue;
+        }
         const float rb = g.rho_box[l];
         const int lox = (int)fminf(fmaxf(bin_coord_f(p.x - rb, g.ox, g.inv_c), 0.f), g.dimx - 1.f);
         const int loy = (int)fminf(fmaxf(bin_coord_f(p.y - rb, g.oy, g.inv_c), 0.f), g.dimy - 1.f);
@@ -350,8 +484,7 @@ __device__ __forceinline__ Best nearest_group(const Grid& g, float3 p, int sub, 
                 const int iz = t / nrow, rem = t - iz * nrow;
                 const int iy = rem / nbx, ix = rem - iy * nbx;
                 const int bx = bx0 + ix, cy = loy + iy, cz = loz + iz;
-                const int bid = find_brick(g, brick_key((uint32_t)bx, (uint32_t)(cy >> kBrickLog2),
-                                                        (uint32_t)(cz >> kBrickLog2)));
+                const int bid = brick_lookup(g, bx, cy >> kBrickLog2, cz >> kBrickLog2);
                 if (bid >= 0) {
                     const int x0 = max(lox, bx << kBrickLog2) & (kBrickDim - 1);
                     const int x1 = min(hix, (bx << kBrickLog2) + kBrickDim - 1) & (kBrickDim - 1);
