@@ -314,26 +314,18 @@ __device__ __forceinline__ uint32_t spread10(uint32_t v) {
     v = (v | (v << 2)) & 0x09249249u;
     return v;
 }
-__global__ void k_source_keys(const float* __restrict__ xyz, int64_t stride, int64_t n,
-                              const PrepState* __restrict__ ps, int centre, float ox, float oy, float oz, float inv_c,
-                              float dimx, float dimy, float dimz, int shift, uint32_t* __restrict__ keys,
-                              uint32_t* __restrict__ vals) {
+// Morton key of a reading point in the reading's OWN frame (cells of edge `cell`, anchored at the first point, 10
+// bits per axis): a rigid transform keeps neighbours together, so the order is computed once per reading
+// (reg_set_source) and serves every initial guess.  Speed only -- results are reported in the caller's order.
+__global__ void k_source_keys(const float* __restrict__ xyz, int64_t stride, int64_t n, float inv_cell,
+                              uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Xf T0;
-#pragma unroll
-    for (int k = 0; k < 12; ++k) T0.m[k] = ps->T0[k];
     const float* p = xyz + i * stride;
-    float x = p[0], y = p[1], z = p[2];
-    if (centre) {
-        x = x - ps->c_read[0];
-        y = y - ps->c_read[1];
-        z = z - ps->c_read[2];
-    }
-    const float3 q = xf_point(T0, x, y, z);
-    const uint32_t bx = (uint32_t)fminf(fmaxf(bin_coord_f(q.x, ox, inv_c), 0.f), dimx - 1.f) >> shift;
-    const uint32_t by = (uint32_t)fminf(fmaxf(bin_coord_f(q.y, oy, inv_c), 0.f), dimy - 1.f) >> shift;
-    const uint32_t bz = (uint32_t)fminf(fmaxf(bin_coord_f(q.z, oz, inv_c), 0.f), dimz - 1.f) >> shift;
+    const float ax = xyz[0], ay = xyz[1], az = xyz[2];
+    const uint32_t bx = (uint32_t)fminf(fmaxf(floorf((p[0] - ax) * inv_cell) + 512.f, 0.f), 1023.f);
+    const uint32_t by = (uint32_t)fminf(fmaxf(floorf((p[1] - ay) * inv_cell) + 512.f, 0.f), 1023.f);
+    const uint32_t bz = (uint32_t)fminf(fmaxf(floorf((p[2] - az) * inv_cell) + 512.f, 0.f), 1023.f);
     keys[i] = spread10(bx) | (spread10(by) << 1) | (spread10(bz) << 2);
     vals[i] = (uint32_t)i;
 }
@@ -2571,6 +2563,26 @@ reg_status reg_set_source(reg_handle* h, const float* xyz, int64_t xyz_stride, c
     HIPCHK(h, h->i_hint.reserve((size_t)n));
     h->s_stride = xyz_stride;
     h->s_nstride = nrm_stride;
+    h->perm = nullptr;
+    if (h->prm.sort_source) {
+        // spatial (Morton) order of the reading, in its own frame: once per reading, not once per registration
+        HIPCHK(h, h->s_keys.reserve((size_t)n * 4));
+        HIPCHK(h, h->s_keys2.reserve((size_t)n * 4));
+        HIPCHK(h, h->s_perm.reserve((size_t)n * 4));
+        HIPCHK(h, h->s_perm2.reserve((size_t)n * 4));
+        const float cell = h->m > 0 ? h->info.cell_size * (float)kBrickDim : 1.0f;
+        k_source_keys<<<grid_for(n), 256, 0, h->stream>>>(h->s_raw.as<float>(), xyz_stride, n, 1.0f / cell,
+                                                          h->s_keys.as<uint32_t>(), h->s_perm.as<uint32_t>());
+        size_t tb = 0;
+        HIPCHK(h, rocprim::radix_sort_pairs(nullptr, tb, h->s_keys.as<uint32_t>(), h->s_keys2.as<uint32_t>(),
+                                            h->s_perm.as<uint32_t>(), h->s_perm2.as<uint32_t>(), (size_t)n, 0, 30,
+                                            h->stream));
+        HIPCHK(h, h->s_tmp.reserve(tb));
+        HIPCHK(h, rocprim::radix_sort_pairs(h->s_tmp.p, tb, h->s_keys.as<uint32_t>(), h->s_keys2.as<uint32_t>(),
+                                            h->s_perm.as<uint32_t>(), h->s_perm2.as<uint32_t>(), (size_t)n, 0, 30,
+                                            h->stream));
+        h->perm = h->s_perm2.as<uint32_t>();
+    }
     return REG_OK;
 }
 
@@ -2637,32 +2649,6 @@ static reg_status prepare_rowmajor(reg_handle* h, const float* T_init_row, const
     h->prep_pending = true;
     pmark("T0+copy");
     const PrepState* ps = h->s_prep.as<PrepState>();
-    h->perm = nullptr;
-    if (h->prm.sort_source) {
-        const Grid& g = h->grid;
-        HIPCHK(h, h->s_keys.reserve((size_t)n * 4));
-        HIPCHK(h, h->s_keys2.reserve((size_t)n * 4));
-        HIPCHK(h, h->s_perm.reserve((size_t)n * 4));
-        HIPCHK(h, h->s_perm2.reserve((size_t)n * 4));
-        // Morton order at brick granularity (7 bits per axis: 3 radix passes instead of 4; finer order buys nothing)
-        int shift = kBrickLog2;
-        while (std::max(g.dimx, std::max(g.dimy, g.dimz)) / (float)(1 << shift) > 128.f) ++shift;
-        k_source_keys<<<grid_for(n), 256, 0, h->stream>>>(h->s_raw.as<float>(), h->s_stride, n, ps, p2pl ? 1 : 0, g.ox, g.oy,
-                                                          g.oz, g.inv_c, g.dimx, g.dimy, g.dimz, shift,
-                                                          h->s_keys.as<uint32_t>(), h->s_perm.as<uint32_t>());
-        pmark("keys");
-        size_t tb = 0;
-        HIPCHK(h, rocprim::radix_sort_pairs(nullptr, tb, h->s_keys.as<uint32_t>(), h->s_keys2.as<uint32_t>(),
-                                            h->s_perm.as<uint32_t>(), h->s_perm2.as<uint32_t>(), (size_t)n, 0, 21,
-                                            h->stream));
-        pmark("sort query");
-        HIPCHK(h, h->s_tmp.reserve(tb));
-        HIPCHK(h, rocprim::radix_sort_pairs(h->s_tmp.p, tb, h->s_keys.as<uint32_t>(), h->s_keys2.as<uint32_t>(),
-                                            h->s_perm.as<uint32_t>(), h->s_perm2.as<uint32_t>(), (size_t)n, 0, 21,
-                                            h->stream));
-        h->perm = h->s_perm2.as<uint32_t>();
-        pmark("sort");
-    }
     k_prepare_source<<<grid_for(n), 256, 0, h->stream>>>(
         h->s_raw.as<float>(), h->s_stride, (p2pl && h->has_snrm) ? h->s_nrm_raw.as<float>() : nullptr, h->s_nstride, n, ps,
         p2pl ? 1 : 0, h->perm, h->s_xyz.as<float4>(), (p2pl && h->has_snrm) ? h->s_nrm.as<float4>() : nullptr,
@@ -3009,7 +2995,7 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
     const bool can_fuse = p2pl && h->prm.disable_fused != 1;
     const bool trimming = p2pl && h->prm.use_trimmed && h->prm.trim_ratio != 1.0f;
     const int kGenericFirst = trimming ? 2 : 1;
-    const int kAhead = getenv("O3D_KAHEAD") ? atoi(getenv("O3D_KAHEAD")) : (fixed > 0 ? 3 : 2);
+    const int kAhead = getenv("O3D_KAHEAD") ? atoi(getenv("O3D_KAHEAD")) : 2;
     const HostMirror* mir = h->h_mirror;
     int generic_left = kGenericFirst;
     const bool trace = getenv("O3D_TRACE") != nullptr;
