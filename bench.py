@@ -240,6 +240,40 @@ def main():
         for r in regs:
             r.close()
 
+    # secondary figure: the GICP cost (the north star's cost function; SURVEY 8d: 72 B/pt + 16 B/pt for the split
+    # kernels) on the same clouds, covariances from the analytic normals.  Never `value`.
+    gicp = None
+    if world == 1 and not force_dist and args.workload in ("c2", "tiny"):
+        pg = capi.default_params()
+        pg.cost = capi.COST_GICP
+        pg.use_trimmed = 0
+        pg.max_dist = 0.5
+        pg.fixed_iters = ITERS
+        pg.device = local_rank
+        greg = capi.Registration(pg)
+        d_tcov = torch.from_numpy(sc.tgt_cov).to(dev)
+        d_scov = torch.from_numpy(sc.src_cov[lo:hi]).to(dev)
+        torch.cuda.synchronize()
+        greg.set_target_device(d_tgt.data_ptr(), 3, n_tgt, None, 3, d_tcov.data_ptr())
+        greg.set_source_device(d_src.data_ptr(), 3, n_src, None, 3, d_scov.data_ptr())
+        for _ in range(2):
+            greg.register(T_init)
+        torch.cuda.synchronize()
+        tg0 = time.perf_counter()
+        g_steps = max(3, args.steps // 4)
+        for _ in range(g_steps):
+            Tg, gres = greg.register(T_init)
+        torch.cuda.synchronize()
+        tg = time.perf_counter() - tg0
+        gt, gr = synth.pose_error(Tg, sc.T_true)
+        gicp = {"value": ITERS * g_steps / tg, "unit": "iter/s", "ms_per_registration": 1e3 * tg / g_steps,
+                "registrations": g_steps, "bytes_per_point": 88,
+                "achieved_GBs_end_to_end": n_src * 88 * ITERS * g_steps / tg / 1e9,
+                "pose_vs_truth": {"trans_m": gt, "rot_rad": gr}, "T": Tg.tolist(),
+                "note": "GICP parity is unpinned against the reference (Open3D 0.15.1 arithmetic not in tree); "
+                        "checked against the float64 oracle in tests/test_gpu_parity.py"}
+        greg.close()
+
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the number comes from
     # the committed rocprofv3 --pmc passes of THIS command (tools/collect_profiles.sh -> profiles/r01_pmc_traffic.json;
     # FETCH_SIZE doubled as the gfx950 guide prescribes and as the k_stream calibration in that file confirms).
@@ -278,6 +312,7 @@ def main():
             "target_build_ms": float(reg.last_result.target_build_ms) if world == 1 else None,
             "band_stalls_last_step": int(reg.last_result.n_band_stalls) if world == 1 else None,
             "batched": batched,
+            "gicp": gicp,
         }
         if not args.no_cpu_baseline:
             cores = os.cpu_count() or 1
@@ -296,6 +331,14 @@ def main():
             et, er = synth.pose_error(T_final, sc.T_true)
             line["pose_vs_oracle"] = {"trans_m": dt, "rot_rad": dr}
             line["pose_vs_truth"] = {"trans_m": et, "rot_rad": er}
+            if gicp is not None:
+                Tgo, gor = orc.icp_gicp(sc.tgt_xyz, sc.tgt_cov, sc.src_xyz, sc.src_cov, max_dist=0.5, fixed_iters=ITERS,
+                                        n_threads=threads)
+                gicp["cpu_oracle_iter_per_s"] = ITERS / gor.loop_seconds   # kd-tree build excluded
+                gdt, gdr = synth.pose_error(np.asarray(gicp["T"], np.float32), Tgo)
+                gicp["pose_vs_oracle"] = {"trans_m": gdt, "rot_rad": gdr}
+        if gicp is not None:
+            gicp.pop("T", None)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
