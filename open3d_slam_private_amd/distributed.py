@@ -218,9 +218,15 @@ class FusedStreamDistributedRegistration(StreamDistributedRegistration):
                 if generic_left > 0 or not settled:
                     self._generic()
                     generic_left = max(generic_left - 1, 0)
+                    enq += 1
                 else:
-                    self._fused()
-                enq += 1
+                    # fixed iteration count: nothing the host could learn changes what has to run -> submit the whole
+                    # rest in one burst (trickle-feeding costs ~6 us per iteration at every kernel boundary);
+                    # a failed band prediction turns what follows into no-ops and is repaired above
+                    burst = (limit - (completed + inflight)) if self.fixed else 1
+                    for _ in range(max(burst, 1)):
+                        self._fused()
+                        enq += 1
                 continue
             if inflight == 0:
                 break
