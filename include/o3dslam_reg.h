@@ -94,6 +94,16 @@ typedef struct {
     int32_t disable_halo;       /* 1: no halo-bin level 0 */
     int32_t lanes_per_point;    /* 0 = default (8); 4 */
     int32_t disable_fused;      /* 1: every iteration on the generic (select-based) path */
+    /* degeneracyAwareness: OptimizedEqualityConstraints (icp.yaml:50-55; ICP.cpp:629-672, 2187-2444;
+       PointToPlane.cpp:459-505): on the FIRST iteration the eigen-directions of the rotation / translation blocks of A
+       are tested for information content (sums of |alignment| over the matched pairs above two cosine thresholds);
+       every iteration then solves with the update constrained to zero along the non-localizable directions.
+       Point-to-plane only.  Inert when every direction is localizable. */
+    int32_t use_xicp;
+    float   xicp_enough;        /* enoughInformationThreshold (250 shipped): sum over alignment > cos(min angle) */
+    float   xicp_insufficient;  /* insufficientInformationThreshold (180 shipped): sum over alignment > cos(strong angle) */
+    float   xicp_min_angle_deg; /* point2NormalMinimalAlignmentAngleThreshold (80 shipped) */
+    float   xicp_strong_angle_deg; /* point2NormalStrongAlignmentAngleThreshold (45 shipped) */
     int32_t reserved[1];
 } reg_params;
 
@@ -113,16 +123,22 @@ typedef struct {
     float   loop_ms;            /* iteration loop of the last reg_register (device time, HIP events) */
     float   T_iter_last[16];    /* final T_iter (column-major): P2PL in the centred frames, GICP == T_out */
     int32_t n_band_stalls;      /* fused path: iterations whose trimmed-band prediction failed and were re-run on the generic path */
-    int32_t reserved;
+    int32_t n_constraints;      /* use_xicp: number of non-localizable directions (0 = plain solve) */
     float   prof_ms[4];         /* params.profile_loop: summed device time (HIP events) of [0] k_match, [1] k_iter_fused launches */
     int32_t prof_launches[4];   /* ... and how many launches that was */
+    /* use_xicp: [0..2] rotation eigen-directions (descending eigenvalue), [3..5] translation; 1 = localizable
+       (LocalizabilityCategory, PointMatcher.h:603-607); all 1 when the analysis is off */
+    int32_t localizable[6];
+    double  xicp_combined[6];   /* the two information sums per direction (ICP.cpp:2128-2155) */
+    double  xicp_high[6];
 } reg_result;
 
 /* ICPChainBase::setDefault (ICP.cpp:100-113): knn 1, eps 0, maxDist inf, Trimmed 0.85,
    Counter 40, Differential 0.001/0.001/3, point-to-plane. */
 REG_API void reg_default_params(reg_params* p);
 /* open3d_slam_ros/param/icp.yaml as shipped (maxDist 0.5, Trimmed 0.9, SurfaceNormal 1.57,
-   Differential 0.001/0.008/3, Counter 30); epsilon is forced to 0 (exact search). */
+   Differential 0.001/0.008/3, Counter 30); epsilon is forced to 0 (exact search).  The degeneracyAwareness
+   thresholds are filled in (250 / 180 / 80 / 45) but use_xicp stays 0: switch it on to run R8x. */
 REG_API void reg_shipped_params(reg_params* p);
 
 REG_API reg_status reg_create(const reg_params* p, reg_handle** out);
@@ -214,6 +230,10 @@ REG_API reg_status reg_dist_poll(reg_handle* h, reg_dist_status* out);
    (PointToPlane.cpp:112-265 solve, :327-381 x -> 4x4; column-major 4x4). */
 REG_API int  reg_host_solve6(const float A[36], const float b[6], float x[6]);
 REG_API void reg_host_x_to_T(const float x[6], float T[16]);
+/* R8x equality-constrained solve (PointToPlane.cpp:459-505, null-space form): flags[k] = 1 keeps eigen-direction k
+   (0-2 rotation block, 3-5 translation block, descending eigenvalue), 0 forbids any update along it.
+   Returns the rank of the reduced system. */
+REG_API int  reg_host_solve6_xicp(const float A[36], const float b[6], const int32_t flags[6], float x[6]);
 REG_API void reg_host_centroid(const float* xyz, int64_t stride, int64_t n, float out[3]);
 
 /* Measurement hook (bench.py roofline object): average device time in ms, by HIP events on the handle's

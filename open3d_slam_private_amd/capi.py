@@ -33,7 +33,9 @@ class RegParams(C.Structure):
                 ("fixed_iters", C.c_int32), ("gicp_rot_eps", C.c_float), ("gicp_trans_eps", C.c_float),
                 ("cell_size", C.c_float), ("device", C.c_int32), ("sort_source", C.c_int32),
                 ("profile_loop", C.c_int32), ("match_variant", C.c_int32), ("debug_flags", C.c_int32), ("disable_halo", C.c_int32),
-                ("lanes_per_point", C.c_int32), ("disable_fused", C.c_int32), ("reserved", C.c_int32 * 1)]
+                ("lanes_per_point", C.c_int32), ("disable_fused", C.c_int32), ("use_xicp", C.c_int32),
+                ("xicp_enough", C.c_float), ("xicp_insufficient", C.c_float), ("xicp_min_angle_deg", C.c_float),
+                ("xicp_strong_angle_deg", C.c_float), ("reserved", C.c_int32 * 1)]
 
 
 class RegResult(C.Structure):
@@ -41,8 +43,9 @@ class RegResult(C.Structure):
                 ("rank_last", C.c_int32), ("n_inliers", C.c_int64), ("n_matched", C.c_int64), ("error", C.c_double),
                 ("fitness", C.c_double), ("inlier_rmse", C.c_double), ("H_last", C.c_float * 36),
                 ("b_last", C.c_float * 6), ("target_build_ms", C.c_float), ("loop_ms", C.c_float),
-                ("T_iter_last", C.c_float * 16), ("n_band_stalls", C.c_int32), ("reserved", C.c_int32),
-                ("prof_ms", C.c_float * 4), ("prof_launches", C.c_int32 * 4)]
+                ("T_iter_last", C.c_float * 16), ("n_band_stalls", C.c_int32), ("n_constraints", C.c_int32),
+                ("prof_ms", C.c_float * 4), ("prof_launches", C.c_int32 * 4), ("localizable", C.c_int32 * 6),
+                ("xicp_combined", C.c_double * 6), ("xicp_high", C.c_double * 6)]
 
 
 class DistStatus(C.Structure):
@@ -62,7 +65,7 @@ EXPORTS = ["reg_default_params", "reg_shipped_params", "reg_create", "reg_destro
            "reg_linearize", "reg_get_correspondences", "reg_match_local", "reg_trim_histogram", "reg_reduce_local",
            "reg_solve_update", "reg_host_solve6", "reg_host_x_to_T", "reg_host_centroid", "reg_get_target_info", "reg_profile_kernels", "reg_source_centroid_sums", "reg_prepare_centroid", "reg_compose",
            "reg_dist_begin", "reg_dist_buffers", "reg_dist_phase", "reg_dist_finish",
-           "reg_dist_fused_buffers", "reg_dist_poll", "reg_estimate_normals"]
+           "reg_dist_fused_buffers", "reg_dist_poll", "reg_estimate_normals", "reg_host_solve6_xicp"]
 
 
 def lib_path() -> str:
@@ -114,6 +117,8 @@ def load_library():
     lib.reg_host_solve6.argtypes = [f32p, f32p, f32p]
     lib.reg_host_solve6.restype = C.c_int
     lib.reg_host_x_to_T.argtypes = [f32p, f32p]
+    lib.reg_host_solve6_xicp.argtypes = [f32p, f32p, vp, f32p]
+    lib.reg_host_solve6_xicp.restype = C.c_int
     lib.reg_host_centroid.argtypes = [f32p, i64, i64, f32p]
     lib.reg_get_target_info.argtypes = [vp, C.POINTER(TargetInfo)]
     lib.reg_profile_kernels.argtypes = [vp, f32p, C.c_int, f32p]
@@ -385,6 +390,13 @@ def solve_update(params: RegParams, sums, T_iter):
 def host_solve6(A, b):
     x = np.zeros(6, np.float32)
     rank = load_library().reg_host_solve6(_ptr(_f32(A).reshape(36)), _ptr(_f32(b)), _ptr(x))
+    return x, rank
+
+
+def host_solve6_xicp(A, b, flags):
+    x = np.zeros(6, np.float32)
+    f = np.ascontiguousarray(flags, np.int32)
+    rank = load_library().reg_host_solve6_xicp(_ptr(_f32(A).reshape(36)), _ptr(_f32(b)), _ptr(f), _ptr(x))
     return x, rank
 
 

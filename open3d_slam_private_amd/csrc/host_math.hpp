@@ -127,6 +127,99 @@ O3D_HD inline int solve6_p2pl(const float* A, const float* b, float* x) {
     return rank;
 }
 
+// ---- R8x: X-ICP localizability (ICP.cpp:1580-1591, 2187-2444; PointToPlane.cpp:459-505) --------------------
+// Eigenvectors of a symmetric 3x3 block in DESCENDING eigenvalue order (the order of JacobiSVD's U for a PSD
+// matrix); V[3*r+k] = component r of eigenvector k.
+O3D_HD inline void eig3_desc(const double* S, double* V) {
+    double M[9], W[9], l[3];
+    for (int i = 0; i < 9; ++i) M[i] = S[i];
+    jacobi_eig_sym(3, M, W, l);
+    int o0 = 0, o1 = 1, o2 = 2;
+    if (l[o1] > l[o0]) { const int t = o0; o0 = o1; o1 = t; }
+    if (l[o2] > l[o0]) { const int t = o0; o0 = o2; o2 = t; }
+    if (l[o2] > l[o1]) { const int t = o1; o1 = o2; o2 = t; }
+    for (int r = 0; r < 3; ++r) {
+        V[3 * r + 0] = W[3 * r + o0];
+        V[3 * r + 1] = W[3 * r + o1];
+        V[3 * r + 2] = W[3 * r + o2];
+    }
+}
+
+// rotation (rows/cols 0-2) and translation (3-5) eigenvectors of the fp32 system matrix (row-major 6x6)
+O3D_HD inline void xicp_eigvecs(const float* A, double* Vr, double* Vt) {
+    double Sr[9], St[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            Sr[3 * i + j] = 0.5 * ((double)A[6 * i + j] + (double)A[6 * j + i]);
+            St[3 * i + j] = 0.5 * ((double)A[6 * (i + 3) + j + 3] + (double)A[6 * (j + 3) + i + 3]);
+        }
+    eig3_desc(Sr, Vr);
+    eig3_desc(St, Vt);
+}
+
+// Equality-constrained solve: no update along the non-localizable eigen-directions (flags[k] == 0).  Null-space form
+// of the reference's (6+c)x(6+c) KKT system: x = Z (Z^T A Z)^-1 Z^T b with Z = the localizable eigenvectors.
+O3D_HD inline int solve6_xicp(const float* A, const float* b, const int* flags, float* x) {
+    double Vr[9], Vt[9], Z[36];
+    xicp_eigvecs(A, Vr, Vt);
+    int m = 0;
+    for (int k = 0; k < 3; ++k)
+        if (flags[k]) {
+            for (int r = 0; r < 6; ++r) Z[6 * r + m] = r < 3 ? Vr[3 * r + k] : 0.0;
+            ++m;
+        }
+    for (int k = 0; k < 3; ++k)
+        if (flags[3 + k]) {
+            for (int r = 0; r < 6; ++r) Z[6 * r + m] = r >= 3 ? Vt[3 * (r - 3) + k] : 0.0;
+            ++m;
+        }
+    for (int i = 0; i < 6; ++i) x[i] = 0.f;
+    if (m == 0) return 0;
+    double AZ[36], M[36], V[36], lam[6], g[6];
+    for (int i = 0; i < 6; ++i)
+        for (int c = 0; c < m; ++c) {
+            double t = 0;
+            for (int j = 0; j < 6; ++j) t += 0.5 * ((double)A[6 * i + j] + (double)A[6 * j + i]) * Z[6 * j + c];
+            AZ[6 * i + c] = t;
+        }
+    for (int a = 0; a < m; ++a) {
+        for (int c = 0; c < m; ++c) {
+            double t = 0;
+            for (int i = 0; i < 6; ++i) t += Z[6 * i + a] * AZ[6 * i + c];
+            M[m * a + c] = t;
+        }
+        double t = 0;
+        for (int i = 0; i < 6; ++i) t += Z[6 * i + a] * (double)b[i];
+        g[a] = t;
+    }
+    for (int a = 0; a < m; ++a)
+        for (int c = a + 1; c < m; ++c) {
+            const double v = 0.5 * (M[m * a + c] + M[m * c + a]);
+            M[m * a + c] = v;
+            M[m * c + a] = v;
+        }
+    jacobi_eig_sym(m, M, V, lam);
+    double lmax = 0;
+    for (int k = 0; k < m; ++k) lmax = fmax(lmax, fabs(lam[k]));
+    const double thr = lmax * (double)m * 1.1920929e-07;
+    double y[6] = {0, 0, 0, 0, 0, 0};
+    int rank = 0;
+    for (int k = 0; k < m; ++k) {
+        if (!(fabs(lam[k]) > thr)) continue;
+        ++rank;
+        double vb = 0;
+        for (int a = 0; a < m; ++a) vb += V[m * a + k] * g[a];
+        vb /= lam[k];
+        for (int a = 0; a < m; ++a) y[a] += V[m * a + k] * vb;
+    }
+    for (int i = 0; i < 6; ++i) {
+        double t = 0;
+        for (int c = 0; c < m; ++c) t += Z[6 * i + c] * y[c];
+        x[i] = (float)t;
+    }
+    return rank;
+}
+
 // x = [rx ry rz tx ty tz] -> row-major 4x4, fp32, one rounding per op (NC10).
 O3D_HD inline void x_to_T(const float* x, float* T) {
     float a = x[0] * x[0], b = x[1] * x[1], c = x[2] * x[2];

@@ -53,6 +53,21 @@ struct IterState {
     unsigned int band_count;  // records appended to the band buffer in this iteration
     unsigned int band_cap;
     int debug_narrow_band;
+    // R8x (X-ICP localizability, OptimizedEqualityConstraints)
+    int xicp_stage;           // 0: off / analysed, 1: analysis pending (first iteration), 2: sums being collected
+    int xicp_nc;              // number of non-localizable directions (constraints)
+    int xicp_flags[6];        // 1 = localizable; rotation eigen-directions 0-2, translation 3-5
+    float xicp_enough, xicp_insufficient, xicp_cos_min, xicp_cos_strong;
+    float xicp_Trd[12];       // T_refMean_dataIn (row-major 3x4): its inverse takes the matched data to the frame it came from
+    double xicp_comb[6], xicp_high[6];   // the information sums of the analysis (reported with every mirror)
+};
+
+// Scratch of the first-iteration localizability analysis.
+struct XicpState {
+    float vr[9], vt[9];       // eigenvectors in the data frame, [k*3 + r]
+    int pad[2];
+    double center[4];         // sum of the matched reading points (data frame) + their count
+    double comb[6], high[6];  // information sums: rotation 0-2, translation 3-5
 };
 
 // What the update kernel mirrors into mapped host memory (the host polls `seq`).
@@ -62,6 +77,9 @@ struct HostMirror {
     int iterations, done, status, rank_last, converged, max_iter_reached, stall, band_count;
     float limit_last, limit_prev, band_lo, band_hi;
     int pad_nband, pad2;
+    int localizable[6];
+    int n_constraints, pad3;
+    double xicp_comb[6], xicp_high[6];
     unsigned long long stamps[8];   // s_memtime stamps of the update kernel (diagnostics only; nothing reads them)
     unsigned long long seq;
 };
@@ -1108,6 +1126,133 @@ __device__ __forceinline__ void block_pick1024(const uint32_t* h, int nb, uint32
 // the outcome into mapped host memory followed by a sequence word the host polls.
 // Multi-GPU fused iteration, between the fused kernel and the all-gather: reduce this rank's accumulator replicas
 // into the header of its contribution block (and clear them), record its band count.
+// ---- R8x first-iteration analysis (ICP.cpp:2187-2444): matched pairs -> data frame, centre, alignment sums ----
+// Vectors in fp32 with one rounding per operation (numeric contract), sums in fp64.
+__device__ __forceinline__ float3 xicp_to_data_frame_point(const float* Trd, const float3 p) {
+    const float q0 = p.x - Trd[3], q1 = p.y - Trd[7], q2 = p.z - Trd[11];
+    float3 r;
+    float a0, a1, a2, sacc;
+    a0 = Trd[0] * q0; a1 = Trd[4] * q1; a2 = Trd[8] * q2; sacc = a0 + a1; r.x = sacc + a2;
+    a0 = Trd[1] * q0; a1 = Trd[5] * q1; a2 = Trd[9] * q2; sacc = a0 + a1; r.y = sacc + a2;
+    a0 = Trd[2] * q0; a1 = Trd[6] * q1; a2 = Trd[10] * q2; sacc = a0 + a1; r.z = sacc + a2;
+    return r;
+}
+__device__ __forceinline__ float3 xicp_to_data_frame_vec(const float* Trd, const float x, const float y, const float z) {
+    float3 r;
+    float a0, a1, a2, sacc;
+    a0 = Trd[0] * x; a1 = Trd[4] * y; a2 = Trd[8] * z; sacc = a0 + a1; r.x = sacc + a2;
+    a0 = Trd[1] * x; a1 = Trd[5] * y; a2 = Trd[9] * z; sacc = a0 + a1; r.y = sacc + a2;
+    a0 = Trd[2] * x; a1 = Trd[6] * y; a2 = Trd[10] * z; sacc = a0 + a1; r.z = sacc + a2;
+    return r;
+}
+
+template <int NV>
+__device__ __forceinline__ void xicp_block_add(double* v, double* dst) {
+    __shared__ double red[4][NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) red[wave][k] = v[k];
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        const double t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        if (t != 0.0) unsafeAtomicAdd(&dst[threadIdx.x], t);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_xicp_center(const float4* __restrict__ src, int64_t n, const IterState* __restrict__ it, const int* __restrict__ pos,
+              const float* __restrict__ w, XicpState* __restrict__ xs) {
+    if (it->done || it->xicp_stage != 2) return;
+    const Xf T = load_xf(it);
+    float Trd[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) Trd[k] = it->xicp_Trd[k];
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (pos[i] < 0 || w[i] == 0.f) continue;
+        const float4 s = src[i];
+        const float3 ps = xicp_to_data_frame_point(Trd, xf_point(T, s.x, s.y, s.z));
+        v[0] += (double)ps.x;
+        v[1] += (double)ps.y;
+        v[2] += (double)ps.z;
+        v[3] += 1.0;
+    }
+    xicp_block_add<4>(v, xs->center);
+}
+
+__global__ void __launch_bounds__(256)
+k_xicp_detect(const float4* __restrict__ src, int64_t n, const IterState* __restrict__ it, const int* __restrict__ pos,
+              const float* __restrict__ w, const float4* __restrict__ tgt_nrm, XicpState* __restrict__ xs) {
+    if (it->done || it->xicp_stage != 2) return;
+    const Xf T = load_xf(it);
+    float Trd[12], vr[9], vt[9];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) Trd[k] = it->xicp_Trd[k];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        vr[k] = xs->vr[k];
+        vt[k] = xs->vt[k];
+    }
+    const double cnt = xs->center[3];
+    float c[3] = {0.f, 0.f, 0.f};
+    if (cnt > 0.0) {
+        c[0] = (float)(xs->center[0] / cnt);
+        c[1] = (float)(xs->center[1] / cnt);
+        c[2] = (float)(xs->center[2] / cnt);
+    }
+    const float cos_min = it->xicp_cos_min, cos_strong = it->xicp_cos_strong;
+    double v[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) v[k] = 0.0;   // comb[0..5], high[0..5]
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int j = pos[i];
+        if (j < 0 || w[i] == 0.f) continue;
+        const float4 s = src[i];
+        float3 ps = xicp_to_data_frame_point(Trd, xf_point(T, s.x, s.y, s.z));
+        ps.x = ps.x - c[0];
+        ps.y = ps.y - c[1];
+        ps.z = ps.z - c[2];
+        const float4 nr = tgt_nrm[j];
+        const float3 nn = xicp_to_data_frame_vec(Trd, nr.x, nr.y, nr.z);
+        float cr[3];
+        float u, q;
+        u = ps.y * nn.z; q = ps.z * nn.y; cr[0] = u - q;
+        u = ps.z * nn.x; q = ps.x * nn.z; cr[1] = u - q;
+        u = ps.x * nn.y; q = ps.y * nn.x; cr[2] = u - q;
+        float a = cr[0] * cr[0], b2 = cr[1] * cr[1];
+        float s2 = a + b2;
+        a = cr[2] * cr[2];
+        s2 = s2 + a;
+        const float nrm = sqrtf(s2);
+        if (!(nrm < 1.0f)) {
+            cr[0] = cr[0] / nrm;
+            cr[1] = cr[1] / nrm;
+            cr[2] = cr[2] / nrm;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float a0 = cr[0] * vr[3 * k], a1 = cr[1] * vr[3 * k + 1], a2 = cr[2] * vr[3 * k + 2];
+            float sacc = a0 + a1;
+            const float ar = fabsf(sacc + a2);
+            a0 = nn.x * vt[3 * k];
+            a1 = nn.y * vt[3 * k + 1];
+            a2 = nn.z * vt[3 * k + 2];
+            sacc = a0 + a1;
+            const float at = fabsf(sacc + a2);
+            if (ar > cos_min) v[k] += (double)ar;
+            if (ar > cos_strong) v[6 + k] += (double)ar;
+            if (at > cos_min) v[3 + k] += (double)at;
+            if (at > cos_strong) v[9 + k] += (double)at;
+        }
+    }
+    xicp_block_add<12>(v, xs->comb);   // comb[6] and high[6] are contiguous
+}
+
 __global__ void __launch_bounds__(64)
 k_pack_contrib(double* __restrict__ acc, const IterState* __restrict__ it, float* __restrict__ contrib) {
     const int c = threadIdx.x;
@@ -1138,7 +1283,12 @@ __device__ __forceinline__ void lds_barrier() {
 __global__ void __launch_bounds__(1024)
 k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it, HostMirror* host,
                 unsigned long long seq, int fused, const float* __restrict__ band, float* __restrict__ w_out,
-                const SelectState* __restrict__ sel, const float* __restrict__ gathered, int n_ranks, int my_rank) {
+                const SelectState* __restrict__ sel, const float* __restrict__ gathered, int n_ranks, int my_rank,
+                XicpState* __restrict__ xs) {
+    // fused: 0 = select-based iteration, 1 = fused iteration (band verification), 2 = R8x finish: the sums are
+    // already in the state (first-iteration localizability analysis done in between), only solve + update
+    const bool finish = fused == 2;
+    if (finish) fused = 0;
     __shared__ double sh[32][kSums];
     __shared__ double tot[kSums];
     __shared__ uint32_t hist[2048 + 64];
@@ -1151,6 +1301,7 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
     __shared__ uint32_t s_cnt, s_csel, s_need_radix;
     __shared__ uint32_t rk_off[65];   // multi-GPU: first global band index of every rank's records (+ total)
     __shared__ uint32_t rk_bad;
+    __shared__ int s_skip_mirror;
     // The whole iteration state is staged in LDS by one coalesced load (every separate `it->` access below would
     // cost an L2 round trip on a single lane); wave 0 writes the modified copy back at the end.  The accumulator
     // rows do not depend on the state, so their loads are issued in the same batch.
@@ -1161,7 +1312,7 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
     const int comp = threadIdx.x & (kSums - 1), part = threadIdx.x / kSums;  // 32 parts x 32 comps
     if (threadIdx.x < kStateWords) s_state[threadIdx.x] = reinterpret_cast<const uint32_t*>(it)[threadIdx.x];
     double t = 0;
-    if (!gathered) {
+    if (!gathered && !finish) {
         const int n_rows = fused ? kAccRows : n_blocks;
         for (int b = part; b < n_rows; b += 32) t += partials[(size_t)b * kSums + comp];
     }
@@ -1235,8 +1386,9 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
         double s = 0;
 #pragma unroll
         for (int p = 0; p < 16; ++p) s += sh[p][threadIdx.x];
-        tot[threadIdx.x] = s;
+        tot[threadIdx.x] = finish ? sit->sums[threadIdx.x] : s;
     }
+    if (threadIdx.x == 0) s_skip_mirror = 0;
     lds_barrier();
     const unsigned long long stA = __builtin_amdgcn_s_memtime();
     unsigned long long stB = stA, stC = stA, sx1 = stA, sx2 = stA, sx3 = stA;
@@ -1437,16 +1589,20 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
         const double q = ajc / pj;
         a = (r == j) ? q : a - arj * q;
     }
-    double xs[6];
+    double xsol[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) xs[i] = __shfl(a, i * 8 + 6);
+    for (int i = 0; i < 6; ++i) xsol[i] = __shfl(a, i * 8 + 6);
     st2 = __builtin_amdgcn_s_memtime();
     if (lane == 0) {
         // band for the next iteration from the limits seen so far
-        const float limit = s_limit;
-        sit->limit_prev = sit->limit_last;
-        sit->limit_last = limit;
-        if (!trim || !(limit < INFINITY)) {
+        const float limit = finish ? sit->limit_last : s_limit;
+        if (!finish) {
+            sit->limit_prev = sit->limit_last;
+            sit->limit_last = limit;
+        }
+        if (finish) {
+            // keep the band computed when the sums were reduced
+        } else if (!trim || !(limit < INFINITY)) {
             sit->band_lo = INFINITY;   // no trimming / nothing to predict from: every finite match is "certainly kept"
             sit->band_hi = INFINITY;
         } else {
@@ -1457,18 +1613,78 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
             sit->band_lo = limit * (1.0f - m);
             sit->band_hi = limit * (1.0f + m);
         }
-        mir_w[100] = (uint32_t)sit->band_count;
+        const int nband_report = (int)sit->band_count;
         sit->band_count = 0;
         sit->stall = 0;
-        if (sit->update) {
+        bool do_update = sit->update != 0;
+        if (!finish && do_update && p2pl && sit->xicp_stage == 1 && tot[28] != 0.0 && xs) {
+            // R8x, first iteration: eigen-directions of the rotation / translation blocks of A, expressed in the frame
+            // the data came from; the analysis kernels that follow collect the information sums, then this kernel
+            // runs again (finish) to decide, solve and update.  Nothing is reported to the host yet.
+            float H[36];
+            int k = 0;
+            for (int i = 0; i < 6; ++i)
+                for (int j = i; j < 6; ++j) {
+                    const float v = (float)tot[k++];
+                    H[6 * i + j] = v;
+                    H[6 * j + i] = v;
+                }
+            double Vr[9], Vt[9];
+            xicp_eigvecs(H, Vr, Vt);
+            for (int kk = 0; kk < 3; ++kk)
+                for (int rr = 0; rr < 3; ++rr) {
+                    float a0 = sit->xicp_Trd[rr] * (float)Vr[kk], a1 = sit->xicp_Trd[4 + rr] * (float)Vr[3 + kk];
+                    float a2 = sit->xicp_Trd[8 + rr] * (float)Vr[6 + kk];
+                    float sacc = a0 + a1;
+                    xs->vr[3 * kk + rr] = sacc + a2;
+                    a0 = sit->xicp_Trd[rr] * (float)Vt[kk];
+                    a1 = sit->xicp_Trd[4 + rr] * (float)Vt[3 + kk];
+                    a2 = sit->xicp_Trd[8 + rr] * (float)Vt[6 + kk];
+                    sacc = a0 + a1;
+                    xs->vt[3 * kk + rr] = sacc + a2;
+                }
+            for (int i = 0; i < 4; ++i) xs->center[i] = 0.0;
+            for (int i = 0; i < 6; ++i) {
+                xs->comb[i] = 0.0;
+                xs->high[i] = 0.0;
+            }
+            sit->xicp_stage = 2;
+            do_update = false;
+            s_skip_mirror = 1;
+        }
+        if (finish && xs) {
+            int nc = 0;
+            for (int i = 0; i < 6; ++i) {
+                const int ok = (xs->comb[i] >= (double)sit->xicp_enough || xs->high[i] >= (double)sit->xicp_insufficient) ? 1 : 0;
+                sit->xicp_flags[i] = ok;
+                sit->xicp_comb[i] = xs->comb[i];
+                sit->xicp_high[i] = xs->high[i];
+                nc += ok ? 0 : 1;
+            }
+            sit->xicp_nc = nc;
+            sit->xicp_stage = 0;
+        }
+        if (do_update) {
             if (tot[28] == 0.0) {
                 sit->status = REG_NO_CORRESPONDENCES;
                 sit->done = 1;
             } else if (p2pl) {
                 float x[6], dT[16], Tn[16];
                 int rank = 6;
-                if (well) {
-                    for (int i = 0; i < 6; ++i) x[i] = (float)xs[i];
+                if (sit->xicp_nc > 0) {
+                    // R8x: no update along the non-localizable eigen-directions of the CURRENT A (PointToPlane.cpp:459-505)
+                    float H[36], b6[6];
+                    int k = 0;
+                    for (int i = 0; i < 6; ++i)
+                        for (int j = i; j < 6; ++j) {
+                            const float v = (float)tot[k++];
+                            H[6 * i + j] = v;
+                            H[6 * j + i] = v;
+                        }
+                    for (int i = 0; i < 6; ++i) b6[i] = -(float)tot[21 + i];
+                    rank = solve6_xicp(H, b6, sit->xicp_flags, x);
+                } else if (well) {
+                    for (int i = 0; i < 6; ++i) x[i] = (float)xsol[i];
                 } else {
                     // ill-conditioned / rank deficient: eigen-solve with the fp32 rank threshold (minimum norm)
                     float H[36], b6[6];
@@ -1497,7 +1713,7 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
                 double dl[6], E[16], Tn[16];
                 int rank = 6;
                 if (well) {
-                    for (int i = 0; i < 6; ++i) dl[i] = xs[i];
+                    for (int i = 0; i < 6; ++i) dl[i] = xsol[i];
                 } else {
                     double Hd[36], g[6];
                     int k = 0;
@@ -1550,7 +1766,14 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
         m->limit_prev = sit->limit_prev;
         m->band_lo = sit->band_lo;
         m->band_hi = sit->band_hi;
-        m->pad_nband = (int)mir_w[100];
+        m->pad_nband = nband_report;
+        for (int i = 0; i < 6; ++i) {
+            m->localizable[i] = sit->xicp_flags[i];
+            m->xicp_comb[i] = sit->xicp_comb[i];
+            m->xicp_high[i] = sit->xicp_high[i];
+        }
+        m->n_constraints = sit->xicp_nc;
+        m->pad3 = 0;
         m->stamps[0] = st1 - st0;
         m->stamps[1] = st2 - st1;
         m->stamps[2] = st3 - st2;
@@ -1565,6 +1788,7 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
     __builtin_amdgcn_wave_barrier();
     // write the modified state back (coalesced); the next kernel of the stream reads it from global memory
     for (int w = lane; w < kStateWords; w += 64) reinterpret_cast<uint32_t*>(it)[w] = s_state[w];
+    if (s_skip_mirror) return;   // R8x analysis pending: the finish pass reports
     constexpr int kMirrorWords = (int)(offsetof(HostMirror, seq) / 4);
     uint32_t* hw = reinterpret_cast<uint32_t*>(host);
     for (int w = lane; w < kMirrorWords; w += 64) hw[w] = mir_w[w];
@@ -1897,6 +2121,8 @@ struct reg_handle {
     bool structure_only = false;   // workspace handle of reg_estimate_normals: bin table only, no attributes
     reg_handle* normals_ws = nullptr;
     DevBuf n_out, n_eig, n_cov, n_ids;
+    DevBuf i_xicp;                 // XicpState (R8x first-iteration analysis)
+    bool xicp_pending = false;     // the next generic iteration is followed by the analysis kernels
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_iter = nullptr;
     bool iter_copy_pending = false;
 
@@ -1984,6 +2210,11 @@ void reg_default_params(reg_params* p) {
     p->cell_size = 0.f;
     p->device = 0;
     p->sort_source = 1;
+    p->use_xicp = 0;
+    p->xicp_enough = 250.f;             // icp.yaml:50-55
+    p->xicp_insufficient = 180.f;
+    p->xicp_min_angle_deg = 80.f;
+    p->xicp_strong_angle_deg = 45.f;
 }
 
 void reg_shipped_params(reg_params* p) {
@@ -2009,6 +2240,7 @@ reg_status reg_create(const reg_params* p, reg_handle** out) {
     if (p->cost != REG_COST_P2PL && p->cost != REG_COST_GICP) return REG_BAD_ARGUMENT;
     if (p->use_trimmed && !(p->trim_ratio >= 0.f && p->trim_ratio <= 1.f)) return REG_BAD_ARGUMENT;
     if (p->fixed_iters <= 0 && p->max_iter <= 0) return REG_BAD_ARGUMENT;
+    if (p->use_xicp && p->cost != REG_COST_P2PL) return REG_BAD_ARGUMENT;   // the analysis expects point-to-plane (ICP.cpp:1118)
     reg_handle* h = new reg_handle();
     h->prm = *p;
     std::memset(&h->info, 0, sizeof(h->info));
@@ -2044,6 +2276,7 @@ void reg_destroy(reg_handle* h) {
     if (!h) return;
     if (h->normals_ws) reg_destroy(h->normals_ws);
     h->n_out.release();
+    h->i_xicp.release();
     h->n_eig.release();
     h->n_cov.release();
     h->n_ids.release();
@@ -2693,6 +2926,23 @@ static reg_status init_iter_state(reg_handle* h, const float* T_row, int update)
     st->trim_ratio = h->prm.trim_ratio;
     st->band_cap = kBandCap;
     st->debug_narrow_band = (h->prm.debug_flags & 8) ? 1 : 0;
+    h->xicp_pending = false;
+    for (int k = 0; k < 6; ++k) st->xicp_flags[k] = 1;
+    if (h->prm.use_xicp && h->prm.cost == REG_COST_P2PL && update) {
+        HIPCHK(h, h->i_xicp.reserve(sizeof(XicpState)));
+        st->xicp_stage = 1;
+        st->xicp_enough = h->prm.xicp_enough;
+        st->xicp_insufficient = h->prm.xicp_insufficient;
+        st->xicp_cos_min = (float)std::cos((double)h->prm.xicp_min_angle_deg * 3.14159265358979323846 / 180.0);
+        st->xicp_cos_strong = (float)std::cos((double)h->prm.xicp_strong_angle_deg * 3.14159265358979323846 / 180.0);
+        // T_refMean_dataIn = T_refIn_refMean^-1 * T_init (ICP.cpp:1067): the frame change of the analysis
+        float A[16], Trd[16];
+        m4_identity(A);
+        for (int k = 0; k < 3; ++k) A[4 * k + 3] = -h->c_ref[k];
+        m4_mul(A, h->T_init, Trd);
+        for (int k = 0; k < 12; ++k) st->xicp_Trd[k] = Trd[k];
+        h->xicp_pending = true;
+    }
     HIPCHK(h, hipMemcpyAsync(h->i_iter.p, st, sizeof(IterState), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipEventRecord(h->ev_iter, h->stream));
     h->iter_copy_pending = true;
@@ -2783,7 +3033,19 @@ static reg_status enqueue_linearize(reg_handle* h, bool want_w, bool limit_from_
     k_reduce_update<<<1, 1024, 0, h->stream>>>(h->i_partials.as<double>(), h->n_blocks, h->i_iter.as<IterState>(),
                                                h->d_mirror, h->seq, 0, nullptr, nullptr,
                                                h->prm.cost == REG_COST_P2PL ? h->i_state.as<SelectState>() : nullptr,
-                                               nullptr, 0, 0);
+                                               nullptr, 0, 0, h->i_xicp.as<XicpState>());
+    if (h->xicp_pending) {
+        // R8x, first iteration: collect the information sums on the matched pairs, then decide + solve + update
+        h->xicp_pending = false;
+        const int blocks = (int)std::min<int64_t>(512, (h->n + 255) / 256);
+        k_xicp_center<<<blocks, 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->n, h->i_iter.as<IterState>(),
+                                                     h->i_pos.as<int>(), h->i_w.as<float>(), h->i_xicp.as<XicpState>());
+        k_xicp_detect<<<blocks, 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->n, h->i_iter.as<IterState>(),
+                                                     h->i_pos.as<int>(), h->i_w.as<float>(), h->t_nrm.as<float4>(),
+                                                     h->i_xicp.as<XicpState>());
+        k_reduce_update<<<1, 1024, 0, h->stream>>>(nullptr, 0, h->i_iter.as<IterState>(), h->d_mirror, h->seq, 2, nullptr,
+                                                   nullptr, nullptr, nullptr, 0, 0, h->i_xicp.as<XicpState>());
+    }
     return REG_OK;
 }
 
@@ -2812,7 +3074,7 @@ static void launch_fused(reg_handle* h, const FilterCfg& f, float* w, uint8_t* h
     prof_mark(h, 1, false);
     ++h->seq;
     k_reduce_update<<<1, 1024, 0, h->stream>>>(h->i_acc.as<double>(), blocks, h->i_iter.as<IterState>(), h->d_mirror,
-                                               h->seq, 1, h->i_band.as<float>(), w, nullptr, nullptr, 0, 0);
+                                               h->seq, 1, h->i_band.as<float>(), w, nullptr, nullptr, 0, 0, nullptr);
 }
 
 static reg_status enqueue_fused(reg_handle* h, bool want_w) {
@@ -3095,6 +3357,12 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
         h->profiling = false;
     }
     res->iterations = mir->iterations;
+    for (int k = 0; k < 6; ++k) {
+        res->localizable[k] = h->prm.use_xicp ? mir->localizable[k] : 1;
+        res->xicp_combined[k] = mir->xicp_comb[k];
+        res->xicp_high[k] = mir->xicp_high[k];
+    }
+    res->n_constraints = h->prm.use_xicp ? mir->n_constraints : 0;
     res->converged = mir->converged;
     res->max_iter_reached = mir->max_iter_reached;
     res->rank_last = mir->rank_last;
@@ -3278,6 +3546,11 @@ reg_status reg_solve_update(const reg_params* p, const double sums[32], const fl
 reg_status reg_dist_begin(reg_handle* h, const float T_start[16]) {
     reg_status s = check_ready(h, true);
     if (s != REG_OK) return s;
+    if (h->prm.use_xicp) {
+        h->err = "use_xicp: the localizability analysis is not available on the distributed path (its information sums "
+                 "are not exchanged between ranks yet)";
+        return REG_BAD_ARGUMENT;
+    }
     float Tr[16];
     if (T_start) {
         col_to_row(T_start, Tr);
@@ -3383,7 +3656,7 @@ reg_status reg_dist_phase(reg_handle* h, int phase) {
             ++h->seq;
             k_reduce_update<<<1, 1024, 0, h->stream>>>(h->i_sums.as<double>(), 1, h->i_iter.as<IterState>(), h->d_mirror,
                                                        h->seq, 0, nullptr, nullptr,
-                                                       h->prm.cost == REG_COST_P2PL ? st : nullptr, nullptr, 0, 0);
+                                                       h->prm.cost == REG_COST_P2PL ? st : nullptr, nullptr, 0, 0, nullptr);
             break;
         case 5: {
             // fused iteration, local half: search + weights + normal equations + band records (into this rank's
@@ -3407,7 +3680,7 @@ reg_status reg_dist_phase(reg_handle* h, int phase) {
             ++h->seq;
             k_reduce_update<<<1, 1024, 0, h->stream>>>(nullptr, 0, h->i_iter.as<IterState>(), h->d_mirror, h->seq, 1,
                                                        nullptr, h->i_w.as<float>(), nullptr, h->d_gathered.as<float>(),
-                                                       h->dist_ranks, h->dist_rank);
+                                                       h->dist_ranks, h->dist_rank, nullptr);
             break;
         default:
             return REG_BAD_ARGUMENT;
@@ -3493,6 +3766,12 @@ reg_status reg_profile_kernels(reg_handle* h, const float T_iter[16], int reps, 
 // ---- host-only exports ----------------------------------------------------------------------------
 
 int reg_host_solve6(const float A[36], const float b[6], float x[6]) { return solve6_p2pl(A, b, x); }
+
+int reg_host_solve6_xicp(const float A[36], const float b[6], const int32_t flags[6], float x[6]) {
+    int f[6];
+    for (int k = 0; k < 6; ++k) f[k] = flags[k];
+    return solve6_xicp(A, b, f, x);
+}
 
 void reg_host_x_to_T(const float x[6], float T[16]) {
     float Tr[16];

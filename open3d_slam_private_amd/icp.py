@@ -135,6 +135,25 @@ class ICP:
                 p.smooth_len = int(cargs.get("smoothLength", 3))
             else:
                 raise NotImplementedError(f"transformation checker {cname}")
+        da = doc.get("degeneracyAwareness")
+        if da:
+            # ICPChainBase::loadAdditionalYAMLContent (ICP.cpp:575-790): only the shipped method is accelerated
+            (dname, dargs), = (da.items() if isinstance(da, dict) else [(da, {})])
+            dargs = dargs or {}
+            if dname == "OptimizedEqualityConstraints":
+                need = ("enoughInformationThreshold", "insufficientInformationThreshold",
+                        "point2NormalMinimalAlignmentAngleThreshold", "point2NormalStrongAlignmentAngleThreshold")
+                if any(k not in dargs for k in need):
+                    raise InvalidParameter("OptimizedEqualityConstraints needs " + ", ".join(need))   # ICP.cpp:632-672
+                p.use_xicp = 1
+                p.xicp_enough = float(dargs[need[0]])
+                p.xicp_insufficient = float(dargs[need[1]])
+                p.xicp_min_angle_deg = float(dargs[need[2]])
+                p.xicp_strong_angle_deg = float(dargs[need[3]])
+            elif dname in ("None", "none", "kNone"):
+                pass
+            else:
+                raise NotImplementedError(f"degeneracyAwareness method {dname}")
         if p.knn != 1:
             raise InvalidParameter("knn must be 1 on the accelerated path")
         self.params = p

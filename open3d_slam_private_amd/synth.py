@@ -214,3 +214,37 @@ def pose_error(T, T_ref):
     # small-angle robust: use the skew part
     s = 0.5 * np.linalg.norm([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
     return dt, float(math.atan2(s, c))
+
+
+def make_corridor(n_src, n_tgt, seed=0, length=40.0, width=3.0, height=2.5, n_end=0, noise=0.005):
+    """Degenerate scene for the localizability tests (R8x): a straight corridor along x (floor, ceiling, two walls)
+    -- translation along x is unobservable -- plus `n_end` target points on an end wall (weak information along x).
+    Returns (tgt_xyz, tgt_nrm, src_xyz, src_nrm) float32; the reading is sampled from the same surfaces."""
+    rng = np.random.default_rng(seed)
+
+    def sample(n, with_end):
+        face = rng.integers(0, 4, size=n)
+        x = rng.uniform(-length / 2, length / 2, size=n)
+        u = rng.uniform(-0.5, 0.5, size=n)
+        p = np.zeros((n, 3))
+        nr = np.zeros((n, 3))
+        p[:, 0] = x
+        fl, ce, wl, wr = face == 0, face == 1, face == 2, face == 3
+        p[fl, 1], p[fl, 2], nr[fl, 2] = u[fl] * width, 0.0, 1.0
+        p[ce, 1], p[ce, 2], nr[ce, 2] = u[ce] * width, height, -1.0
+        p[wl, 1], p[wl, 2], nr[wl, 1] = -width / 2, (u[wl] + 0.5) * height, 1.0
+        p[wr, 1], p[wr, 2], nr[wr, 1] = width / 2, (u[wr] + 0.5) * height, -1.0
+        if with_end:
+            e = np.zeros((with_end, 3))
+            e[:, 0] = length / 2
+            e[:, 1] = rng.uniform(-0.5, 0.5, size=with_end) * width
+            e[:, 2] = rng.uniform(0, 1, size=with_end) * height
+            en = np.zeros((with_end, 3))
+            en[:, 0] = -1.0
+            p, nr = np.concatenate([p, e]), np.concatenate([nr, en])
+        p = p + rng.normal(scale=noise, size=p.shape)
+        return p.astype(np.float32), nr.astype(np.float32)
+
+    tgt, tn = sample(n_tgt, n_end)
+    src, sn = sample(n_src, n_end)
+    return tgt, tn, src, sn

@@ -559,6 +559,210 @@ ORC_API int orc_solve6(const float A[36], const float b[6], float x[6]) {
     return rank;
 }
 
+/* ------------------------------------------------------------------------- */
+/* R8x: X-ICP localizability (shipped icp.yaml:50-55, OptimizedEqualityConstraints)                      */
+/*   detection  ICP.cpp:2187-2444 (+2128-2155 sums, 1580-1591 3x3 eigen-analysis, 1669-1695 crosses)     */
+/*   solve      ErrorMinimizers/PointToPlane.cpp:459-505,569-626,756-778                                  */
+/* PARITY UNPINNED: the reference's localizability unit tests are empty (utest/ui/localizability).        */
+/* ------------------------------------------------------------------------- */
+
+/* eigenvectors of a symmetric 3x3 block in DESCENDING eigenvalue order (= the order of JacobiSVD's U
+   for a PSD matrix); V[3*r+k] = component r of eigenvector k */
+static void eig3_desc(const double S[9], double V[9], double lam[3]) {
+    double M[9], W[9], l[3];
+    memcpy(M, S, sizeof(M));
+    jacobi_eig(3, M, W, l);
+    int o[3] = {0, 1, 2};
+    for (int a = 0; a < 3; ++a)
+        for (int b = a + 1; b < 3; ++b)
+            if (l[o[b]] > l[o[a]]) {
+                int t = o[a];
+                o[a] = o[b];
+                o[b] = t;
+            }
+    for (int k = 0; k < 3; ++k) {
+        lam[k] = l[o[k]];
+        for (int r = 0; r < 3; ++r) V[3 * r + k] = W[3 * r + o[k]];
+    }
+}
+
+/* rotation (rows/cols 0-2) and translation (3-5) eigenvectors of the fp32 system matrix */
+ORC_API void orc_xicp_eigvecs(const float A[36], double Vr[9], double Vt[9]) {
+    double Sr[9], St[9], lam[3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            Sr[3 * i + j] = 0.5 * ((double)A[6 * i + j] + (double)A[6 * j + i]);
+            St[3 * i + j] = 0.5 * ((double)A[6 * (i + 3) + j + 3] + (double)A[6 * (j + 3) + i + 3]);
+        }
+    eig3_desc(Sr, Vr, lam);
+    eig3_desc(St, Vt, lam);
+}
+
+/* Equality-constrained solve: the update must have no component along the non-localizable eigenvectors
+   (constraint value 0, ICP.cpp:2326,2373).  flags[0..2]: rotation eigenvector k localizable (1) or not (0),
+   flags[3..5]: translation.  The reference solves the (6+c)x(6+c) KKT system; with orthonormal constraint
+   directions that is the null-space solution x = Z (Z^T A Z)^-1 Z^T b, Z = the localizable eigenvectors
+   (identical whenever the KKT matrix is non-singular; minimum norm over the retained subspace otherwise).
+   Returns the rank of the reduced system. */
+ORC_API int orc_solve6_xicp(const float A[36], const float b[6], const int32_t flags[6], float x[6]) {
+    double Vr[9], Vt[9];
+    orc_xicp_eigvecs(A, Vr, Vt);
+    double Z[36];
+    int m = 0;
+    for (int k = 0; k < 3; ++k)
+        if (flags[k]) {
+            for (int r = 0; r < 6; ++r) Z[6 * r + m] = r < 3 ? Vr[3 * r + k] : 0.0;
+            ++m;
+        }
+    for (int k = 0; k < 3; ++k)
+        if (flags[3 + k]) {
+            for (int r = 0; r < 6; ++r) Z[6 * r + m] = r >= 3 ? Vt[3 * (r - 3) + k] : 0.0;
+            ++m;
+        }
+    for (int i = 0; i < 6; ++i) x[i] = 0.f;
+    if (m == 0) return 0;
+    double Hr[36], g[6], AZ[36];
+    for (int i = 0; i < 6; ++i)
+        for (int c = 0; c < m; ++c) {
+            double t = 0;
+            for (int j = 0; j < 6; ++j) t += 0.5 * ((double)A[6 * i + j] + (double)A[6 * j + i]) * Z[6 * j + c];
+            AZ[6 * i + c] = t;
+        }
+    for (int a = 0; a < m; ++a) {
+        for (int c = 0; c < m; ++c) {
+            double t = 0;
+            for (int i = 0; i < 6; ++i) t += Z[6 * i + a] * AZ[6 * i + c];
+            Hr[m * a + c] = t;
+        }
+        double t = 0;
+        for (int i = 0; i < 6; ++i) t += Z[6 * i + a] * (double)b[i];
+        g[a] = t;
+    }
+    double M[36], V[36], lam[6];
+    for (int a = 0; a < m; ++a)
+        for (int c = 0; c < m; ++c) M[m * a + c] = 0.5 * (Hr[m * a + c] + Hr[m * c + a]);
+    jacobi_eig(m, M, V, lam);
+    double lmax = 0;
+    for (int k = 0; k < m; ++k)
+        if (fabs(lam[k]) > lmax) lmax = fabs(lam[k]);
+    const double thr = lmax * (double)m * 1.1920929e-07;
+    double y[6] = {0, 0, 0, 0, 0, 0};
+    int rank = 0;
+    for (int k = 0; k < m; ++k) {
+        if (!(fabs(lam[k]) > thr)) continue;
+        ++rank;
+        double vb = 0;
+        for (int a = 0; a < m; ++a) vb += V[m * a + k] * g[a];
+        vb /= lam[k];
+        for (int a = 0; a < m; ++a) y[a] += V[m * a + k] * vb;
+    }
+    for (int i = 0; i < 6; ++i) {
+        double t = 0;
+        for (int c = 0; c < m; ++c) t += Z[6 * i + c] * y[c];
+        x[i] = (float)t;
+    }
+    return rank;
+}
+
+/* Localizability detection on the matched pairs of the first iteration.
+   rd: reading in the refMean frame (T_iter applied by the caller = identity at iteration 0), ids/w: matches and
+   outlier weights, tgt_nrm: reference normals, T_rd: T_refMean_dataIn (row-major; its inverse takes the data back
+   to the frame it came from, ICP.cpp:2239).  Vectors in fp32 (one rounding per operation), sums in fp64.
+   comb/high[0..2] rotation, [3..5] translation; flags likewise. */
+ORC_API void orc_xicp_detect(const float* rd, const float* tgt_nrm, int64_t tnrm_stride, const float T_iter[16],
+                             const int32_t* ids, const float* w, int64_t n, const float T_rd[16], const float A[36],
+                             float enough, float insufficient, float cos_min, float cos_strong, int32_t flags[6],
+                             double comb[6], double high[6]) {
+    double Vr[9], Vt[9];
+    orc_xicp_eigvecs(A, Vr, Vt);
+    /* eigenvectors in the data frame: v' = R^T v */
+    float vr[3][3], vt[3][3];
+    for (int k = 0; k < 3; ++k)
+        for (int r = 0; r < 3; ++r) {
+            float a0 = T_rd[4 * 0 + r] * (float)Vr[3 * 0 + k], a1 = T_rd[4 * 1 + r] * (float)Vr[3 * 1 + k];
+            float a2 = T_rd[4 * 2 + r] * (float)Vr[3 * 2 + k];
+            float sacc = a0 + a1;
+            vr[k][r] = sacc + a2;
+            a0 = T_rd[4 * 0 + r] * (float)Vt[3 * 0 + k];
+            a1 = T_rd[4 * 1 + r] * (float)Vt[3 * 1 + k];
+            a2 = T_rd[4 * 2 + r] * (float)Vt[3 * 2 + k];
+            sacc = a0 + a1;
+            vt[k][r] = sacc + a2;
+        }
+    /* pass 1: centre of the matched reading points in the data frame */
+    double cs[3] = {0, 0, 0};
+    int64_t cnt = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (ids[i] < 0 || w[i] == 0.f) continue;
+        float p[3], q[3];
+        xform_point(T_iter, rd + 3 * i, p);
+        for (int k = 0; k < 3; ++k) q[k] = p[k] - T_rd[4 * k + 3];
+        for (int r = 0; r < 3; ++r) {
+            float a0 = T_rd[4 * 0 + r] * q[0], a1 = T_rd[4 * 1 + r] * q[1], a2 = T_rd[4 * 2 + r] * q[2];
+            float sacc = a0 + a1;
+            cs[r] += (double)(sacc + a2);
+        }
+        ++cnt;
+    }
+    float c[3] = {0.f, 0.f, 0.f};
+    if (cnt > 0)
+        for (int r = 0; r < 3; ++r) c[r] = (float)(cs[r] / (double)cnt);
+    for (int k = 0; k < 6; ++k) comb[k] = high[k] = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (ids[i] < 0 || w[i] == 0.f) continue;
+        float p[3], q[3], ps[3], nn[3];
+        xform_point(T_iter, rd + 3 * i, p);
+        for (int k = 0; k < 3; ++k) q[k] = p[k] - T_rd[4 * k + 3];
+        const float* nr = tgt_nrm + (int64_t)ids[i] * tnrm_stride;
+        for (int r = 0; r < 3; ++r) {
+            float a0 = T_rd[4 * 0 + r] * q[0], a1 = T_rd[4 * 1 + r] * q[1], a2 = T_rd[4 * 2 + r] * q[2];
+            float sacc = a0 + a1;
+            ps[r] = (sacc + a2) - c[r];
+            a0 = T_rd[4 * 0 + r] * nr[0];
+            a1 = T_rd[4 * 1 + r] * nr[1];
+            a2 = T_rd[4 * 2 + r] * nr[2];
+            sacc = a0 + a1;
+            nn[r] = sacc + a2;
+        }
+        float cr[3];
+        {
+            float u = ps[1] * nn[2], v = ps[2] * nn[1];
+            cr[0] = u - v;
+            u = ps[2] * nn[0];
+            v = ps[0] * nn[2];
+            cr[1] = u - v;
+            u = ps[0] * nn[1];
+            v = ps[1] * nn[0];
+            cr[2] = u - v;
+        }
+        float a = cr[0] * cr[0], b2 = cr[1] * cr[1];
+        float s2 = a + b2;
+        a = cr[2] * cr[2];
+        s2 = s2 + a;
+        const float nrm = sqrtf(s2);
+        if (!(nrm < 1.0f)) {
+            cr[0] = cr[0] / nrm;
+            cr[1] = cr[1] / nrm;
+            cr[2] = cr[2] / nrm;
+        }
+        for (int k = 0; k < 3; ++k) {
+            float a0 = cr[0] * vr[k][0], a1 = cr[1] * vr[k][1], a2 = cr[2] * vr[k][2];
+            float sacc = a0 + a1;
+            const float ar = fabsf(sacc + a2);
+            a0 = nn[0] * vt[k][0];
+            a1 = nn[1] * vt[k][1];
+            a2 = nn[2] * vt[k][2];
+            sacc = a0 + a1;
+            const float at = fabsf(sacc + a2);
+            if (ar > cos_min) comb[k] += (double)ar;
+            if (ar > cos_strong) high[k] += (double)ar;
+            if (at > cos_min) comb[3 + k] += (double)at;
+            if (at > cos_strong) high[3 + k] += (double)at;
+        }
+    }
+    for (int k = 0; k < 6; ++k) flags[k] = (comb[k] >= (double)enough || high[k] >= (double)insufficient) ? 1 : 0;
+}
+
 /* x = [rx ry rz tx ty tz] -> 4x4 row-major (PointToPlane.cpp:327-381), fp32 (NC10) */
 ORC_API void orc_x_to_T(const float x[6], float T[16]) {
     float a = x[0] * x[0];
@@ -671,6 +875,10 @@ typedef struct {
     int32_t smooth_len;
     int32_t fixed_iters;    /* >0: run exactly this many iterations, ignore checkers (throughput runs) */
     int32_t n_threads;
+    /* R8x (degeneracyAwareness: OptimizedEqualityConstraints) */
+    int32_t use_xicp;
+    float xicp_enough, xicp_insufficient;   /* information thresholds (250 / 180 shipped) */
+    float xicp_cos_min, xicp_cos_strong;    /* cos of the alignment angle thresholds (80 / 45 degrees shipped) */
 } orc_params;
 
 typedef struct {
@@ -685,6 +893,10 @@ typedef struct {
     float T_iter[16];       /* in the centred frames */
     float T_refMean_readMean[16];
     double loop_seconds;    /* wall time of the iteration loop only (kd-tree build excluded) */
+    int32_t localizable[6]; /* R8x flags: rotation eigenvectors 0-2, translation 3-5 (all 1 when R8x is off) */
+    int32_t n_constraints;
+    int32_t pad_;
+    double xicp_combined[6], xicp_high[6];
 } orc_result;
 
 /* Full registration, R1-R10.  tgt_* must carry normals; src normals only needed for ORC_F_NORMAL.
@@ -694,6 +906,7 @@ ORC_API int orc_icp_p2pl(const float* tgt_xyz, int64_t tgt_stride, const float* 
                          int64_t snrm_stride, int64_t n, const float T_init[16], const orc_params* P,
                          float T_out[16], orc_result* res) {
     memset(res, 0, sizeof(*res));
+    for (int k = 0; k < 6; ++k) res->localizable[k] = 1;
     memcpy(T_out, T_init, 64);
     if (m == 0) {
         res->status = 1;
@@ -764,7 +977,20 @@ ORC_API int orc_icp_p2pl(const float* tgt_xyz, int64_t tgt_stride, const float* 
             break;
         }
         float x[6], dT[16];
-        orc_solve6(res->A_last, res->b_last, x);
+        if (P->use_xicp && count == 0) {
+            /* first iteration only (ICP.cpp:2221-2226): which eigen-directions carry enough information */
+            float T_rd[16];
+            mat4_mul(T_refIn_refMean_inv, T_init, T_rd); /* T_refMean_dataIn (ICP.cpp:1067) */
+            orc_xicp_detect(rd, tgt_nrm, tnrm_stride, T_iter, ids, w, n, T_rd, res->A_last, P->xicp_enough,
+                            P->xicp_insufficient, P->xicp_cos_min, P->xicp_cos_strong, res->localizable,
+                            res->xicp_combined, res->xicp_high);
+            res->n_constraints = 0;
+            for (int k = 0; k < 6; ++k) res->n_constraints += res->localizable[k] ? 0 : 1;
+        }
+        if (P->use_xicp && res->n_constraints > 0)
+            orc_solve6_xicp(res->A_last, res->b_last, res->localizable, x);
+        else
+            orc_solve6(res->A_last, res->b_last, x);
         orc_x_to_T(x, dT);
         mat4_mul(dT, T_iter, T_iter);
         ++count;

@@ -26,14 +26,18 @@ class Filters(C.Structure):
 class Params(C.Structure):
     _fields_ = [("max_dist", C.c_float), ("filt", Filters), ("max_iter", C.c_int32),
                 ("min_diff_rot", C.c_float), ("min_diff_trans", C.c_float), ("smooth_len", C.c_int32),
-                ("fixed_iters", C.c_int32), ("n_threads", C.c_int32)]
+                ("fixed_iters", C.c_int32), ("n_threads", C.c_int32),
+                ("use_xicp", C.c_int32), ("xicp_enough", C.c_float), ("xicp_insufficient", C.c_float),
+                ("xicp_cos_min", C.c_float), ("xicp_cos_strong", C.c_float)]
 
 
 class Result(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32), ("max_iter_reached", C.c_int32),
                 ("status", C.c_int32), ("n_kept_last", C.c_int64), ("err_last", C.c_double),
                 ("A_last", C.c_float * 36), ("b_last", C.c_float * 6), ("T_iter", C.c_float * 16),
-                ("T_refMean_readMean", C.c_float * 16), ("loop_seconds", C.c_double)]
+                ("T_refMean_readMean", C.c_float * 16), ("loop_seconds", C.c_double),
+                ("localizable", C.c_int32 * 6), ("n_constraints", C.c_int32), ("pad_", C.c_int32),
+                ("xicp_combined", C.c_double * 6), ("xicp_high", C.c_double * 6)]
 
 
 def build(force: bool = False) -> str:
@@ -181,8 +185,9 @@ def x_to_T(x):
 
 def icp_p2pl(tgt_xyz, tgt_nrm, src_xyz, src_nrm=None, T_init=None, *, max_dist=math.inf, trim_ratio=None,
              max_normal_angle=None, outlier_max_dist=None, max_iter=40, min_diff_rot=0.001, min_diff_trans=0.001,
-             smooth_len=3, fixed_iters=0, n_threads=1):
-    """Full reference-chain registration (R1-R10).  Returns (T 4x4 float32, Result)."""
+             smooth_len=3, fixed_iters=0, n_threads=1, xicp=None):
+    """Full reference-chain registration (R1-R10).  Returns (T 4x4 float32, Result).
+    xicp: None, or (enough, insufficient, min_angle_deg, strong_angle_deg) = R8x OptimizedEqualityConstraints."""
     tgt, tn, src = _f32(tgt_xyz), _f32(tgt_nrm), _f32(src_xyz)
     sn = _f32(src_nrm) if src_nrm is not None else None
     T0 = _f32(np.eye(4) if T_init is None else T_init).reshape(16)
@@ -191,6 +196,11 @@ def icp_p2pl(tgt_xyz, tgt_nrm, src_xyz, src_nrm=None, T_init=None, *, max_dist=m
     P.filt = make_filters(trim_ratio, max_normal_angle, outlier_max_dist)
     P.max_iter, P.min_diff_rot, P.min_diff_trans, P.smooth_len = max_iter, min_diff_rot, min_diff_trans, smooth_len
     P.fixed_iters, P.n_threads = fixed_iters, n_threads
+    if xicp is not None:
+        P.use_xicp = 1
+        P.xicp_enough, P.xicp_insufficient = float(xicp[0]), float(xicp[1])
+        P.xicp_cos_min = float(np.cos(np.float32(xicp[2]) * np.float32(np.pi) / np.float32(180.0), dtype=np.float32))
+        P.xicp_cos_strong = float(np.cos(np.float32(xicp[3]) * np.float32(np.pi) / np.float32(180.0), dtype=np.float32))
     if (P.filt.flags & F_NORMAL) and sn is None:
         raise ValueError("InvalidField: SurfaceNormalOutlierFilter needs 'normals' on the reading")
     T = np.zeros(16, np.float32)
@@ -251,3 +261,20 @@ def surface_normals(xyz, k, max_dist=math.inf, viewpoint=None, regularise=False,
     lib().orc_surface_normals(_p(x), C.c_int64(x.shape[1]), C.c_int64(n), C.c_int(k), C.c_float(max_dist), _p(vp),
                               C.c_int(1 if regularise else 0), _p(nrm), _p(ev), _p(cov), _p(ids), C.c_int(n_threads))
     return nrm, ev, cov, ids
+
+
+def solve6_xicp(A, b, flags):
+    """Equality-constrained 6x6 solve of R8x (null-space form).  Returns (x float32[6], rank of the reduced system)."""
+    A_, b_ = _f32(A).reshape(36), _f32(b).reshape(6)
+    f = np.ascontiguousarray(flags, np.int32)
+    x = np.zeros(6, np.float32)
+    lib().orc_solve6_xicp.restype = C.c_int
+    r = lib().orc_solve6_xicp(_p(A_), _p(b_), _p(f), _p(x))
+    return x, int(r)
+
+
+def xicp_eigvecs(A):
+    A_ = _f32(A).reshape(36)
+    Vr, Vt = np.zeros(9), np.zeros(9)
+    lib().orc_xicp_eigvecs(_p(A_), _p(Vr), _p(Vt))
+    return Vr.reshape(3, 3), Vt.reshape(3, 3)
