@@ -274,6 +274,31 @@ def main():
                         "checked against the float64 oracle in tests/test_gpu_parity.py"}
         greg.close()
 
+    # secondary figure: the same workload with the shipped degeneracyAwareness (R8x: first-iteration localizability
+    # analysis + constrained solve) switched on.  Never `value` (SURVEY 8d defines the measured chain without it).
+    xicp = None
+    if world == 1 and not force_dist and args.workload in ("c2", "tiny"):
+        px = capi.shipped_params()
+        px.fixed_iters = ITERS
+        px.device = local_rank
+        px.use_xicp = 1
+        xreg = capi.Registration(px)
+        xreg.set_target_device(d_tgt.data_ptr(), 3, n_tgt, d_tnrm.data_ptr(), 3)
+        xreg.set_source_device(d_src.data_ptr(), 3, n_src, d_snrm.data_ptr(), 3)
+        for _ in range(2):
+            xreg.register(T_init)
+        torch.cuda.synchronize()
+        tx0 = time.perf_counter()
+        x_steps = max(3, args.steps // 4)
+        for _ in range(x_steps):
+            Tx, xres = xreg.register(T_init)
+        torch.cuda.synchronize()
+        tx = time.perf_counter() - tx0
+        xicp = {"value": ITERS * x_steps / tx, "unit": "iter/s", "ms_per_registration": 1e3 * tx / x_steps,
+                "localizable": list(xres.localizable), "n_constraints": int(xres.n_constraints),
+                "same_pose_as_plain_chain": bool(np.array_equal(Tx, T_final))}
+        xreg.close()
+
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the number comes from
     # the committed rocprofv3 --pmc passes of THIS command (tools/collect_profiles.sh -> profiles/r01_pmc_traffic.json;
     # FETCH_SIZE doubled as the gfx950 guide prescribes and as the k_stream calibration in that file confirms).
@@ -313,6 +338,7 @@ def main():
             "band_stalls_last_step": int(reg.last_result.n_band_stalls) if world == 1 else None,
             "batched": batched,
             "gicp": gicp,
+            "xicp": xicp,
         }
         if not args.no_cpu_baseline:
             cores = os.cpu_count() or 1

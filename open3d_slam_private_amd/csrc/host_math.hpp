@@ -97,6 +97,53 @@ O3D_HD inline void jacobi_eig_sym(int n, double* A, double* V, double* lam) {
     for (int i = 0; i < n; ++i) lam[i] = A[i * n + i];
 }
 
+// Fixed-size 3x3 variant of the cyclic Jacobi iteration above: constant indices keep A and V in registers on the
+// device (the generic routine indexes at run time, which puts its arrays into scratch memory: 40 us per call on one
+// lane), and the sweep loop stops as soon as the off-diagonal mass is below fp64 resolution relative to the diagonal
+// (quadratic convergence: further sweeps would not change a bit of the result).
+template <int P, int Q>
+O3D_HD inline void jacobi3_rotate(double* A, double* V) {
+    const double apq = A[3 * P + Q];
+    if (fabs(apq) < 1e-300) return;
+    const double theta = (A[3 * Q + Q] - A[3 * P + P]) / (2.0 * apq);
+    const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+    const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double akp = A[3 * k + P], akq = A[3 * k + Q];
+        A[3 * k + P] = c * akp - s * akq;
+        A[3 * k + Q] = s * akp + c * akq;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double apk = A[3 * P + k], aqk = A[3 * Q + k];
+        A[3 * P + k] = c * apk - s * aqk;
+        A[3 * Q + k] = s * apk + c * aqk;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double vkp = V[3 * k + P], vkq = V[3 * k + Q];
+        V[3 * k + P] = c * vkp - s * vkq;
+        V[3 * k + Q] = s * vkp + c * vkq;
+    }
+}
+O3D_HD inline void jacobi_eig_sym3(double* A, double* V, double* lam) {
+    V[0] = 1.0; V[1] = 0.0; V[2] = 0.0;
+    V[3] = 0.0; V[4] = 1.0; V[5] = 0.0;
+    V[6] = 0.0; V[7] = 0.0; V[8] = 1.0;
+    for (int sweep = 0; sweep < 32; ++sweep) {
+        const double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
+        const double dg = A[0] * A[0] + A[4] * A[4] + A[8] * A[8];
+        if (off < 1e-300 || off <= 1e-34 * dg) break;
+        jacobi3_rotate<0, 1>(A, V);
+        jacobi3_rotate<0, 2>(A, V);
+        jacobi3_rotate<1, 2>(A, V);
+    }
+    lam[0] = A[0];
+    lam[1] = A[4];
+    lam[2] = A[8];
+}
+
 // rel_thr: eigenvalues <= rel_thr * max are treated as zero.
 O3D_HD inline int solve_sym6(const double* H, const double* g, double* x, double rel_thr) {
     double M[36], V[36], lam[6];
@@ -133,7 +180,7 @@ O3D_HD inline int solve6_p2pl(const float* A, const float* b, float* x) {
 O3D_HD inline void eig3_desc(const double* S, double* V) {
     double M[9], W[9], l[3];
     for (int i = 0; i < 9; ++i) M[i] = S[i];
-    jacobi_eig_sym(3, M, W, l);
+    jacobi_eig_sym3(M, W, l);
     int o0 = 0, o1 = 1, o2 = 2;
     if (l[o1] > l[o0]) { const int t = o0; o0 = o1; o1 = t; }
     if (l[o2] > l[o0]) { const int t = o0; o0 = o2; o2 = t; }

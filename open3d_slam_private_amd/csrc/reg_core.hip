@@ -2023,7 +2023,7 @@ k_knn_pca(Grid g, const float* __restrict__ raw_xyz, int64_t raw_stride, int64_t
         u = dz * dz; C[5] = C[5] + u;
     }
     double M[9] = {C[0], C[1], C[2], C[1], C[3], C[4], C[2], C[4], C[5]}, V[9], lam[3];
-    jacobi_eig_sym(3, M, V, lam);
+    jacobi_eig_sym3(M, V, lam);
     int o0 = 0, o1 = 1, o2 = 2;
     if (lam[o1] < lam[o0]) { const int t = o0; o0 = o1; o1 = t; }
     if (lam[o2] < lam[o0]) { const int t = o0; o0 = o2; o2 = t; }

@@ -7,6 +7,7 @@ reps = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 sc = synth.make_scene(n_src, n_tgt, seed=1236)
 p = capi.shipped_params(); p.fixed_iters = 20
 if os.environ.get('CELL'): p.cell_size = float(os.environ['CELL'])
+if os.environ.get('XICP'): p.use_xicp = 1
 reg = capi.Registration(p)
 reg.set_target(sc.tgt_xyz, sc.tgt_nrm); reg.set_source(sc.src_xyz, sc.src_nrm)
 ms = []
@@ -15,4 +16,5 @@ for r in range(reps):
         os.environ['O3D_TRACE'] = '1'
     T, res = reg.register(np.eye(4))
     ms.append(res.loop_ms)
+print("localizable", list(res.localizable), "constraints", res.n_constraints)
 print("loop_ms", " ".join(f"{m:.3f}" for m in ms), "stalls", res.n_band_stalls, "iters", res.iterations)
