@@ -261,6 +261,34 @@ REG_API reg_status reg_estimate_normals(reg_handle* h, const float* xyz, int64_t
                                         float* normals, float* eigvals, float* covs, int32_t* ids,
                                         int64_t* n_rescanned);
 
+/* ---- next row: target-side preparation on the device ------------------------------------------
+   Replaces, in front of reg_set_target, what the mapper does on the host every referenceCloudSettingPeriod_:
+     open3d_slam/src/ScanToMapRegistration.cpp:90-96   cropSubmap: scanMatcherCropper_->setPose(mapToRangeSensor); crop(map)
+     open3d_slam/src/croppers.cpp:76-106               CroppingVolume::crop: order-preserving copy of the points (+ normals,
+                                                       covariances) with isWithinVolume(p)
+     open3d_slam/src/croppers.cpp:118-170              the volumes: MaxRadius |p-t| <= r; MinRadius |p-t| >= r; MinMaxRadius;
+                                                       Cylinder z in [minZ,maxZ] (absolute) and |(p-t).xy| <= r; all in double
+     open3d_utils/open3d_conversions/src/open3d_conversions.cpp:57-118  open3dToPointmatcher: fp64 AoS -> fp32 features / normals
+       ("This is time consuming", Mapper.cpp:336)
+   xyz / normals: m x 3 doubles (std::vector<Eigen::Vector3d>::data()); covs: m x 9 doubles (Matrix3d, symmetric) or NULL.
+   The kept points keep their order; correspondence ids reported later index the CROPPED cloud (as in the reference,
+   whose matcher only ever sees the patch); reg_get_target_source_indices maps them back. */
+typedef enum {
+    REG_CROP_NONE = 0, REG_CROP_MAX_RADIUS = 1, REG_CROP_MIN_RADIUS = 2, REG_CROP_MIN_MAX_RADIUS = 3, REG_CROP_CYLINDER = 4
+} reg_crop_type;
+typedef struct {
+    int32_t type;          /* reg_crop_type */
+    int32_t reserved;
+    double  center[3];     /* pose_.translation() of the cropper (mapToRangeSensor) */
+    double  radius_min;    /* MinRadius / MinMaxRadius */
+    double  radius_max;    /* MaxRadius / MinMaxRadius / Cylinder radius */
+    double  min_z, max_z;  /* Cylinder */
+} reg_crop;
+REG_API reg_status reg_set_target_f64(reg_handle* h, const double* xyz, const double* normals, const double* covs,
+                                      int64_t m, int on_device, const reg_crop* crop, int64_t* n_kept);
+/* idx[n_kept]: position of every kept point in the cloud given to reg_set_target_f64 */
+REG_API reg_status reg_get_target_source_indices(reg_handle* h, int32_t* idx);
+
 /* Introspection of the search structure (tests, DESIGN.md numbers). */
 typedef struct {
     int64_t n_points;

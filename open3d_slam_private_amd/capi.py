@@ -48,6 +48,14 @@ class RegResult(C.Structure):
                 ("xicp_combined", C.c_double * 6), ("xicp_high", C.c_double * 6)]
 
 
+class RegCrop(C.Structure):
+    _fields_ = [("type", C.c_int32), ("reserved", C.c_int32), ("center", C.c_double * 3), ("radius_min", C.c_double),
+                ("radius_max", C.c_double), ("min_z", C.c_double), ("max_z", C.c_double)]
+
+
+CROP_NONE, CROP_MAX_RADIUS, CROP_MIN_RADIUS, CROP_MIN_MAX_RADIUS, CROP_CYLINDER = 0, 1, 2, 3, 4
+
+
 class DistStatus(C.Structure):
     _fields_ = [("sequences_done", C.c_int64), ("sequences_enqueued", C.c_int64), ("iterations", C.c_int32),
                 ("done", C.c_int32), ("stall", C.c_int32), ("stream_idle", C.c_int32), ("limit_last", C.c_float),
@@ -65,7 +73,8 @@ EXPORTS = ["reg_default_params", "reg_shipped_params", "reg_create", "reg_destro
            "reg_linearize", "reg_get_correspondences", "reg_match_local", "reg_trim_histogram", "reg_reduce_local",
            "reg_solve_update", "reg_host_solve6", "reg_host_x_to_T", "reg_host_centroid", "reg_get_target_info", "reg_profile_kernels", "reg_source_centroid_sums", "reg_prepare_centroid", "reg_compose",
            "reg_dist_begin", "reg_dist_buffers", "reg_dist_phase", "reg_dist_finish",
-           "reg_dist_fused_buffers", "reg_dist_poll", "reg_estimate_normals", "reg_host_solve6_xicp"]
+           "reg_dist_fused_buffers", "reg_dist_poll", "reg_estimate_normals", "reg_host_solve6_xicp",
+           "reg_set_target_f64", "reg_get_target_source_indices"]
 
 
 def lib_path() -> str:
@@ -119,6 +128,8 @@ def load_library():
     lib.reg_host_x_to_T.argtypes = [f32p, f32p]
     lib.reg_host_solve6_xicp.argtypes = [f32p, f32p, vp, f32p]
     lib.reg_host_solve6_xicp.restype = C.c_int
+    lib.reg_set_target_f64.argtypes = [vp, vp, vp, vp, i64, C.c_int, C.POINTER(RegCrop), C.POINTER(C.c_int64)]
+    lib.reg_get_target_source_indices.argtypes = [vp, vp]
     lib.reg_host_centroid.argtypes = [f32p, i64, i64, f32p]
     lib.reg_get_target_info.argtypes = [vp, C.POINTER(TargetInfo)]
     lib.reg_profile_kernels.argtypes = [vp, f32p, C.c_int, f32p]
@@ -219,6 +230,53 @@ class Registration:
         m = xyz.shape[0] if xyz.ndim == 2 else 0
         self._check(self._lib.reg_set_target(self._h, _ptr(xyz), xyz.shape[1] if xyz.ndim == 2 else 3, _ptr(nrm),
                                              nrm.shape[1] if nrm is not None else 3, _ptr(cov), m, 0))
+
+    def set_target_f64(self, xyz, normals=None, covs=None, crop=None):
+        """Target-side preparation on the device (croppers.cpp:76-170 + open3d_conversions.cpp:57-118): fp64 AoS cloud,
+        optional cropping volume `crop` = dict(type=, center=, radius_min=, radius_max=, min_z=, max_z=).
+        Returns the number of points kept."""
+        x = np.ascontiguousarray(xyz, np.float64)
+        nr = np.ascontiguousarray(normals, np.float64) if normals is not None else None
+        cv = np.ascontiguousarray(covs, np.float64).reshape(-1, 9) if covs is not None else None
+        c = None
+        if crop is not None:
+            c = RegCrop()
+            c.type = int(crop.get("type", CROP_NONE))
+            for k in range(3):
+                c.center[k] = float(crop.get("center", (0, 0, 0))[k])
+            c.radius_min = float(crop.get("radius_min", 0.0))
+            c.radius_max = float(crop.get("radius_max", 0.0))
+            c.min_z, c.max_z = float(crop.get("min_z", 0.0)), float(crop.get("max_z", 0.0))
+        kept = C.c_int64(0)
+        st = self._lib.reg_set_target_f64(self._h, _ptr(x), _ptr(nr), _ptr(cv), x.shape[0] if x.ndim == 2 else 0, 0,
+                                          C.byref(c) if c is not None else None, C.byref(kept))
+        self.n_target_kept = int(kept.value)
+        self._check(st)
+        return self.n_target_kept
+
+    def set_target_f64_device(self, xyz_ptr, m, nrm_ptr=None, cov_ptr=None, crop=None):
+        """As set_target_f64 with the fp64 cloud already resident in HBM (m x 3 doubles; normals m x 3; covs m x 9)."""
+        c = None
+        if crop is not None:
+            c = RegCrop()
+            c.type = int(crop.get("type", CROP_NONE))
+            for k in range(3):
+                c.center[k] = float(crop.get("center", (0, 0, 0))[k])
+            c.radius_min = float(crop.get("radius_min", 0.0))
+            c.radius_max = float(crop.get("radius_max", 0.0))
+            c.min_z, c.max_z = float(crop.get("min_z", 0.0)), float(crop.get("max_z", 0.0))
+        kept = C.c_int64(0)
+        st = self._lib.reg_set_target_f64(self._h, C.c_void_p(xyz_ptr), C.c_void_p(nrm_ptr) if nrm_ptr else None,
+                                          C.c_void_p(cov_ptr) if cov_ptr else None, m, 1,
+                                          C.byref(c) if c is not None else None, C.byref(kept))
+        self.n_target_kept = int(kept.value)
+        self._check(st)
+        return self.n_target_kept
+
+    def target_source_indices(self):
+        idx = np.empty(self.n_target_kept, np.int32)
+        self._check(self._lib.reg_get_target_source_indices(self._h, _ptr(idx)))
+        return idx
 
     def set_source(self, xyz, normals=None, covs=None):
         xyz = _f32(xyz)

@@ -1126,6 +1126,63 @@ __device__ __forceinline__ void block_pick1024(const uint32_t* h, int nb, uint32
 // the outcome into mapped host memory followed by a sequence word the host polls.
 // Multi-GPU fused iteration, between the fused kernel and the all-gather: reduce this rank's accumulator replicas
 // into the header of its contribution block (and clear them), record its band count.
+// ---- target-side preparation: crop (croppers.cpp:76-170) + fp64 -> fp32 (open3d_conversions.cpp:57-118)
+struct CropCfg {
+    int type;
+    double cx, cy, cz, rmin, rmax, zmin, zmax;
+};
+__device__ __forceinline__ bool crop_inside(const CropCfg& c, double x, double y, double z) {
+    if (c.type == REG_CROP_NONE) return true;
+    const double dx = x - c.cx, dy = y - c.cy, dz = z - c.cz;
+    if (c.type == REG_CROP_CYLINDER) {
+        double a = dx * dx;
+        double b = dy * dy;
+        const double d = sqrt(a + b);
+        return z >= c.zmin && z <= c.zmax && d <= c.rmax;
+    }
+    double a = dx * dx;
+    double b = dy * dy;
+    double s2 = a + b;
+    a = dz * dz;
+    s2 = s2 + a;
+    const double d = sqrt(s2);
+    if (c.type == REG_CROP_MAX_RADIUS) return d <= c.rmax;
+    if (c.type == REG_CROP_MIN_RADIUS) return d >= c.rmin;
+    return d <= c.rmax && d >= c.rmin;
+}
+__global__ void k_crop_flags(const double* __restrict__ xyz, int64_t m, CropCfg c, uint32_t* __restrict__ flags) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    flags[i] = crop_inside(c, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]) ? 1u : 0u;
+}
+// offs = exclusive scan of flags: order-preserving compaction + conversion
+__global__ void k_crop_gather(const double* __restrict__ xyz, const double* __restrict__ nrm, const double* __restrict__ cov,
+                              int64_t m, const uint32_t* __restrict__ flags, const uint32_t* __restrict__ offs,
+                              float* __restrict__ oxyz, float* __restrict__ onrm, float* __restrict__ ocov,
+                              int32_t* __restrict__ oidx) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= m || !flags[i]) return;
+    const size_t o = offs[i];
+    oxyz[3 * o + 0] = (float)xyz[3 * i + 0];
+    oxyz[3 * o + 1] = (float)xyz[3 * i + 1];
+    oxyz[3 * o + 2] = (float)xyz[3 * i + 2];
+    if (nrm) {
+        onrm[3 * o + 0] = (float)nrm[3 * i + 0];
+        onrm[3 * o + 1] = (float)nrm[3 * i + 1];
+        onrm[3 * o + 2] = (float)nrm[3 * i + 2];
+    }
+    if (cov) {
+        const double* c = cov + 9 * i;   // Matrix3d, symmetric: xx xy xz / . yy yz / . . zz
+        ocov[6 * o + 0] = (float)c[0];
+        ocov[6 * o + 1] = (float)c[1];
+        ocov[6 * o + 2] = (float)c[2];
+        ocov[6 * o + 3] = (float)c[4];
+        ocov[6 * o + 4] = (float)c[5];
+        ocov[6 * o + 5] = (float)c[8];
+    }
+    oidx[o] = (int32_t)i;
+}
+
 // ---- R8x first-iteration analysis (ICP.cpp:2187-2444): matched pairs -> data frame, centre, alignment sums ----
 // Vectors in fp32 with one rounding per operation (numeric contract), sums in fp64.
 __device__ __forceinline__ float3 xicp_to_data_frame_point(const float* Trd, const float3 p) {
@@ -2122,6 +2179,8 @@ struct reg_handle {
     reg_handle* normals_ws = nullptr;
     DevBuf n_out, n_eig, n_cov, n_ids;
     DevBuf i_xicp;                 // XicpState (R8x first-iteration analysis)
+    DevBuf c_in_xyz, c_in_nrm, c_in_cov, c_flags, c_offs, c_xyz, c_nrm, c_cov, c_idx;   // reg_set_target_f64
+    int64_t crop_kept = 0;
     bool xicp_pending = false;     // the next generic iteration is followed by the analysis kernels
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_iter = nullptr;
     bool iter_copy_pending = false;
@@ -2277,6 +2336,7 @@ void reg_destroy(reg_handle* h) {
     if (h->normals_ws) reg_destroy(h->normals_ws);
     h->n_out.release();
     h->i_xicp.release();
+    for (DevBuf* b : {&h->c_in_xyz, &h->c_in_nrm, &h->c_in_cov, &h->c_flags, &h->c_offs, &h->c_xyz, &h->c_nrm, &h->c_cov, &h->c_idx}) b->release();
     h->n_eig.release();
     h->n_cov.release();
     h->n_ids.release();
@@ -2538,6 +2598,7 @@ reg_status reg_set_target(reg_handle* h, const float* xyz, int64_t xyz_stride, c
     if (!h) return REG_BAD_ARGUMENT;
     if (!h->device_ok) return REG_DEVICE_ERROR;
     h->m = 0;
+    h->crop_kept = 0;
     h->have_match = false;
     if (m <= 0) {
         h->err = "The reference point cloud is empty";
@@ -2654,6 +2715,95 @@ reg_status reg_set_target(reg_handle* h, const float* xyz, int64_t xyz_stride, c
     h->info.origin[0] = bmin[0];
     h->info.origin[1] = bmin[1];
     h->info.origin[2] = bmin[2];
+    return REG_OK;
+}
+
+reg_status reg_set_target_f64(reg_handle* h, const double* xyz, const double* normals, const double* covs, int64_t m,
+                              int on_device, const reg_crop* crop, int64_t* n_kept) {
+    if (!h) return REG_BAD_ARGUMENT;
+    if (!h->device_ok) return REG_DEVICE_ERROR;
+    if (n_kept) *n_kept = 0;
+    h->crop_kept = 0;
+    if (m <= 0) {
+        h->m = 0;
+        h->err = "The reference point cloud is empty";
+        return REG_EMPTY_TARGET;
+    }
+    if (!xyz || m > 0x7fffffffLL) return REG_BAD_ARGUMENT;
+    CropCfg c;
+    std::memset(&c, 0, sizeof(c));
+    if (crop) {
+        if (crop->type < REG_CROP_NONE || crop->type > REG_CROP_CYLINDER) return REG_BAD_ARGUMENT;
+        c.type = crop->type;
+        c.cx = crop->center[0];
+        c.cy = crop->center[1];
+        c.cz = crop->center[2];
+        c.rmin = crop->radius_min;
+        c.rmax = crop->radius_max;
+        c.zmin = crop->min_z;
+        c.zmax = crop->max_z;
+    }
+    HIPCHK(h, hipSetDevice(h->prm.device));
+    const double *d_xyz = xyz, *d_nrm = normals, *d_cov = covs;
+    if (!on_device) {
+        HIPCHK(h, h->c_in_xyz.reserve((size_t)m * 24));
+        HIPCHK(h, hipMemcpyAsync(h->c_in_xyz.p, xyz, (size_t)m * 24, hipMemcpyHostToDevice, h->stream));
+        d_xyz = h->c_in_xyz.as<double>();
+        if (normals) {
+            HIPCHK(h, h->c_in_nrm.reserve((size_t)m * 24));
+            HIPCHK(h, hipMemcpyAsync(h->c_in_nrm.p, normals, (size_t)m * 24, hipMemcpyHostToDevice, h->stream));
+            d_nrm = h->c_in_nrm.as<double>();
+        }
+        if (covs) {
+            HIPCHK(h, h->c_in_cov.reserve((size_t)m * 72));
+            HIPCHK(h, hipMemcpyAsync(h->c_in_cov.p, covs, (size_t)m * 72, hipMemcpyHostToDevice, h->stream));
+            d_cov = h->c_in_cov.as<double>();
+        }
+    }
+    HIPCHK(h, h->c_flags.reserve((size_t)m * 4));
+    HIPCHK(h, h->c_offs.reserve((size_t)m * 4));
+    k_crop_flags<<<grid_for(m), 256, 0, h->stream>>>(d_xyz, m, c, h->c_flags.as<uint32_t>());
+    size_t tb = 0;
+    HIPCHK(h, rocprim::exclusive_scan(nullptr, tb, h->c_flags.as<uint32_t>(), h->c_offs.as<uint32_t>(), 0u, (size_t)m,
+                                      rocprim::plus<uint32_t>(), h->stream));
+    HIPCHK(h, h->t_tmp.reserve(tb));
+    HIPCHK(h, rocprim::exclusive_scan(h->t_tmp.p, tb, h->c_flags.as<uint32_t>(), h->c_offs.as<uint32_t>(), 0u, (size_t)m,
+                                      rocprim::plus<uint32_t>(), h->stream));
+    uint32_t last[2] = {0, 0};
+    HIPCHK(h, hipMemcpyAsync(&last[0], h->c_offs.as<uint32_t>() + (m - 1), 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(&last[1], h->c_flags.as<uint32_t>() + (m - 1), 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const int64_t kept = (int64_t)last[0] + (int64_t)last[1];
+    if (n_kept) *n_kept = kept;
+    if (kept == 0) {
+        h->m = 0;
+        h->err = "The reference point cloud is empty (no point inside the cropping volume)";   // ScanToMapRegistration.cpp:94
+        return REG_EMPTY_TARGET;
+    }
+    HIPCHK(h, h->c_xyz.reserve((size_t)kept * 12));
+    if (d_nrm) HIPCHK(h, h->c_nrm.reserve((size_t)kept * 12));
+    if (d_cov) HIPCHK(h, h->c_cov.reserve((size_t)kept * 24));
+    HIPCHK(h, h->c_idx.reserve((size_t)kept * 4));
+    k_crop_gather<<<grid_for(m), 256, 0, h->stream>>>(d_xyz, d_nrm, d_cov, m, h->c_flags.as<uint32_t>(),
+                                                      h->c_offs.as<uint32_t>(), h->c_xyz.as<float>(),
+                                                      d_nrm ? h->c_nrm.as<float>() : nullptr,
+                                                      d_cov ? h->c_cov.as<float>() : nullptr, h->c_idx.as<int32_t>());
+    const reg_status s = reg_set_target(h, h->c_xyz.as<float>(), 3, d_nrm ? h->c_nrm.as<float>() : nullptr, 3,
+                                        d_cov ? h->c_cov.as<float>() : nullptr, kept, 1);
+    if (s == REG_OK) h->crop_kept = kept;
+    return s;
+}
+
+reg_status reg_get_target_source_indices(reg_handle* h, int32_t* idx) {
+    if (!h || !idx) return REG_BAD_ARGUMENT;
+    if (!h->device_ok) return REG_DEVICE_ERROR;
+    if (h->crop_kept <= 0 || h->crop_kept != h->m) {
+        h->err = "the current reference was not set through reg_set_target_f64";
+        return REG_NOT_CONFIGURED;
+    }
+    HIPCHK(h, hipSetDevice(h->prm.device));
+    HIPCHK(h, hipMemcpyAsync(idx, h->c_idx.p, (size_t)h->crop_kept * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return REG_OK;
 }
 

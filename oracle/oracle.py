@@ -278,3 +278,21 @@ def xicp_eigvecs(A):
     Vr, Vt = np.zeros(9), np.zeros(9)
     lib().orc_xicp_eigvecs(_p(A_), _p(Vr), _p(Vt))
     return Vr.reshape(3, 3), Vt.reshape(3, 3)
+
+
+def crop_mask(xyz, crop_type, center=(0.0, 0.0, 0.0), radius_min=0.0, radius_max=0.0, min_z=0.0, max_z=0.0):
+    """CroppingVolume::isWithinVolume (open3d_slam/src/croppers.cpp:118-170) in float64, operation by operation:
+    1 MaxRadius |p-t| <= r; 2 MinRadius |p-t| >= r; 3 MinMaxRadius; 4 Cylinder z in [minZ, maxZ] and |(p-t).xy| <= r."""
+    p = np.asarray(xyz, np.float64)
+    if crop_type == 0:
+        return np.ones(p.shape[0], bool)
+    d = p - np.asarray(center, np.float64)[None]
+    if crop_type == 4:
+        r = np.sqrt(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1])
+        return (p[:, 2] >= min_z) & (p[:, 2] <= max_z) & (r <= radius_max)
+    r = np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2])
+    if crop_type == 1:
+        return r <= radius_max
+    if crop_type == 2:
+        return r >= radius_min
+    return (r <= radius_max) & (r >= radius_min)
