@@ -16,4 +16,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/normals -- python t
 # timeline of one warm registration (gaps between kernels)
 rocprofv3 --kernel-trace --output-format csv -d $OUT/timeline -- python tools/tools_reg1.py 100000 1000000 4 > $OUT/timeline_run.log 2>&1
 python tools/tools_timeline.py $OUT/timeline > $OUT/timeline.txt
+# target-side preparation (crop + fp64->fp32 + build), 5 M points; and the plain bench line of this build
+python tools/tools_target_prep.py 5000000 > $OUT/target_prep.log 2>&1
+python bench.py > $OUT/bench_plain.json 2> $OUT/bench_plain.err
 python tools/summarise_profiles.py $OUT

@@ -75,6 +75,15 @@ if nst:
     for line in open(os.path.join(out, "normals.log")):
         if line.startswith(("GPU", "CPU")):
             open(os.path.join(dst, "r01_normals_1M_k10_line.txt"), "a").write(line)
+tp = os.path.join(out, "target_prep.log")
+if os.path.exists(tp):
+    with open(os.path.join(dst, "r01_target_prep_5M_line.txt"), "w") as fh:
+        fh.writelines(l for l in open(tp) if l.startswith(("GPU", "host")))
+bp = os.path.join(out, "bench_plain.json")
+if os.path.exists(bp):
+    for line in open(bp):
+        if line.startswith('{"metric"'):
+            open(os.path.join(dst, "r01_bench_c2_line_unprofiled.json"), "w").write(line)
 tl = os.path.join(out, "timeline.txt")
 if os.path.exists(tl):
     shutil.copy(tl, os.path.join(dst, "r01_registration_timeline.txt"))
