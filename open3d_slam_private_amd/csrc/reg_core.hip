@@ -169,11 +169,25 @@ __global__ void k_center_bbox(const float* __restrict__ xyz, int64_t stride, int
             mn[k] = fminf(mn[k], __shfl_down(mn[k], o));
             mx[k] = fmaxf(mx[k], __shfl_down(mx[k], o));
         }
+    // same-address atomics serialise (measured: 49 k of them on 6 words cost 0.5 ms): one set per workgroup only
+    __shared__ float red[6][4];
+    const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0)
         for (int k = 0; k < 3; ++k) {
-            atomicMin(&bbox[k], f2ord(mn[k]));
-            atomicMax(&bbox[3 + k], f2ord(mx[k]));
+            red[k][wave] = mn[k];
+            red[3 + k][wave] = mx[k];
         }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int k = threadIdx.x;
+        const int nw = (int)(blockDim.x >> 6);
+        float v = red[k][0];
+        for (int w = 1; w < nw; ++w) v = k < 3 ? fminf(v, red[k][w]) : fmaxf(v, red[k][w]);
+        if (k < 3)
+            atomicMin(&bbox[k], f2ord(v));
+        else
+            atomicMax(&bbox[k], f2ord(v));
+    }
 }
 
 // sort key = (brick z,y,x | bin-in-brick z,y,x)
@@ -247,7 +261,9 @@ __global__ void k_fill_tables(const uint64_t* __restrict__ keys, const uint32_t*
         }
     }
     const uint32_t old = atomicAdd(&counts[(size_t)bid * kBrickCells + local], 1u);
-    if (old == 0) atomicAdd(occupied, 1u);
+    // one aggregated atomic per wave on the single "occupied bins" word (same-address atomics serialise)
+    const unsigned long long first = __ballot(old == 0);
+    if (first && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)first) - 1)) atomicAdd(occupied, (uint32_t)__popcll(first));
 }
 
 // Halo bins: every reference point is listed in each bin whose box, grown by rho_h, contains it.
@@ -2652,7 +2668,7 @@ reg_status reg_set_target(reg_handle* h, const float* xyz, int64_t xyz_stride, c
     bb_init[0] = bb_init[1] = bb_init[2] = 0x7f800000;                    // +inf
     bb_init[3] = bb_init[4] = bb_init[5] = (int)(0xff800000u ^ 0x7fffffffu);  // -inf
     HIPCHK(h, hipMemcpyAsync(h->t_misc.p, bb_init, sizeof(bb_init), hipMemcpyHostToDevice, h->stream));
-    const int blocks = (int)std::min<int64_t>(2048, (m + 255) / 256);
+    const int blocks = (int)std::min<int64_t>(512, (m + 255) / 256);
     k_center_bbox<<<blocks, 256, 0, h->stream>>>(d_xyz, xyz_stride, m, c[0], c[1], c[2], h->t_centred.as<float4>(),
                                                  h->t_misc.as<int>());
     int bb[6];
