@@ -289,6 +289,19 @@ REG_API reg_status reg_set_target_f64(reg_handle* h, const double* xyz, const do
 /* idx[n_kept]: position of every kept point in the cloud given to reg_set_target_f64 */
 REG_API reg_status reg_get_target_source_indices(reg_handle* h, int32_t* idx);
 
+/* Map maintenance half of the same row: voxelizeWithinCroppingVolume (open3d_slam/src/helpers.cpp:117-192), which
+   Submap::insertScan runs on the whole map after every inserted scan (Submap.cpp:39-96).  Points outside `volume` are
+   copied through in their order; points inside are bucketed by voxel index floor(p * (1/voxel_size)) per axis
+   (VoxelHashMap.hpp:48-51) and replaced by one averaged point per occupied voxel: sums in double in index order
+   (AccumulatedPoint, helpers.cpp:30-72: NaN normals are skipped, the averaged normal is re-normalised, covariances are
+   averaged).  The reference emits the voxels in std::unordered_map order (unspecified); here they follow the outside
+   points in ascending (z, y, x) voxel index.  Inputs / outputs: m x 3 (x 9 for covs) doubles, host or device
+   (on_device); the output arrays must hold m points.  voxel_size <= 0 copies the cloud through. */
+REG_API reg_status reg_voxelize_within_volume(reg_handle* h, const double* xyz, const double* normals, const double* covs,
+                                              int64_t m, int on_device, const reg_crop* volume, double voxel_size,
+                                              double* out_xyz, double* out_normals, double* out_covs, int64_t* n_out,
+                                              int64_t* n_outside);
+
 /* Introspection of the search structure (tests, DESIGN.md numbers). */
 typedef struct {
     int64_t n_points;

@@ -74,7 +74,7 @@ EXPORTS = ["reg_default_params", "reg_shipped_params", "reg_create", "reg_destro
            "reg_solve_update", "reg_host_solve6", "reg_host_x_to_T", "reg_host_centroid", "reg_get_target_info", "reg_profile_kernels", "reg_source_centroid_sums", "reg_prepare_centroid", "reg_compose",
            "reg_dist_begin", "reg_dist_buffers", "reg_dist_phase", "reg_dist_finish",
            "reg_dist_fused_buffers", "reg_dist_poll", "reg_estimate_normals", "reg_host_solve6_xicp",
-           "reg_set_target_f64", "reg_get_target_source_indices"]
+           "reg_set_target_f64", "reg_get_target_source_indices", "reg_voxelize_within_volume"]
 
 
 def lib_path() -> str:
@@ -130,6 +130,8 @@ def load_library():
     lib.reg_host_solve6_xicp.restype = C.c_int
     lib.reg_set_target_f64.argtypes = [vp, vp, vp, vp, i64, C.c_int, C.POINTER(RegCrop), C.POINTER(C.c_int64)]
     lib.reg_get_target_source_indices.argtypes = [vp, vp]
+    lib.reg_voxelize_within_volume.argtypes = [vp, vp, vp, vp, i64, C.c_int, C.POINTER(RegCrop), C.c_double, vp, vp, vp,
+                                               C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.reg_host_centroid.argtypes = [f32p, i64, i64, f32p]
     lib.reg_get_target_info.argtypes = [vp, C.POINTER(TargetInfo)]
     lib.reg_profile_kernels.argtypes = [vp, f32p, C.c_int, f32p]
@@ -272,6 +274,37 @@ class Registration:
         self.n_target_kept = int(kept.value)
         self._check(st)
         return self.n_target_kept
+
+    @staticmethod
+    def _crop_struct(crop):
+        if crop is None:
+            return None
+        c = RegCrop()
+        c.type = int(crop.get("type", CROP_NONE))
+        for k in range(3):
+            c.center[k] = float(crop.get("center", (0, 0, 0))[k])
+        c.radius_min = float(crop.get("radius_min", 0.0))
+        c.radius_max = float(crop.get("radius_max", 0.0))
+        c.min_z, c.max_z = float(crop.get("min_z", 0.0)), float(crop.get("max_z", 0.0))
+        return c
+
+    def voxelize_within_volume(self, xyz, voxel_size, volume=None, normals=None, covs=None):
+        """voxelizeWithinCroppingVolume (helpers.cpp:117-192) on the device.  Returns (xyz, normals, covs, n_outside):
+        the first n_outside rows are the untouched points outside `volume`, the rest one averaged point per voxel."""
+        x = np.ascontiguousarray(xyz, np.float64)
+        m = x.shape[0]
+        nr = np.ascontiguousarray(normals, np.float64) if normals is not None else None
+        cv = np.ascontiguousarray(covs, np.float64).reshape(-1, 9) if covs is not None else None
+        ox = np.empty((m, 3), np.float64)
+        on = np.empty((m, 3), np.float64) if nr is not None else None
+        oc = np.empty((m, 9), np.float64) if cv is not None else None
+        c = self._crop_struct(volume)
+        n_out, n_outside = C.c_int64(0), C.c_int64(0)
+        self._check(self._lib.reg_voxelize_within_volume(self._h, _ptr(x), _ptr(nr), _ptr(cv), m, 0,
+                                                         C.byref(c) if c is not None else None, float(voxel_size), _ptr(ox),
+                                                         _ptr(on), _ptr(oc), C.byref(n_out), C.byref(n_outside)))
+        k = int(n_out.value)
+        return ox[:k], (on[:k] if on is not None else None), (oc[:k] if oc is not None else None), int(n_outside.value)
 
     def target_source_indices(self):
         idx = np.empty(self.n_target_kept, np.int32)

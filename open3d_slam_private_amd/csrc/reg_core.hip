@@ -1199,6 +1199,98 @@ __global__ void k_crop_gather(const double* __restrict__ xyz, const double* __re
     oidx[o] = (int32_t)i;
 }
 
+// ---- voxelizeWithinCroppingVolume (helpers.cpp:117-192) ----
+constexpr int kVoxBits = 21;                       // voxel index bits per axis in the sort key (offset binary)
+constexpr long long kVoxOff = 1ll << (kVoxBits - 1);
+__global__ void k_vox_classify(const double* __restrict__ xyz, int64_t m, CropCfg c, double inv, uint32_t* __restrict__ f_in,
+                               uint32_t* __restrict__ f_out, uint32_t* __restrict__ overflow) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    const bool in = crop_inside(c, x, y, z);
+    f_in[i] = in ? 1u : 0u;
+    f_out[i] = in ? 0u : 1u;
+    if (in) {
+        const double vx = floor(x * inv), vy = floor(y * inv), vz = floor(z * inv);
+        if (!(fabs(vx) < (double)kVoxOff && fabs(vy) < (double)kVoxOff && fabs(vz) < (double)kVoxOff)) atomicOr(overflow, 1u);
+    }
+}
+__global__ void k_vox_scatter(const double* __restrict__ xyz, const double* __restrict__ nrm, const double* __restrict__ cov,
+                              int64_t m, double inv, const uint32_t* __restrict__ f_in, const uint32_t* __restrict__ o_in,
+                              const uint32_t* __restrict__ o_out, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                              double* __restrict__ oxyz, double* __restrict__ onrm, double* __restrict__ ocov) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    if (f_in[i]) {
+        const long long vx = (long long)floor(xyz[3 * i] * inv) + kVoxOff;
+        const long long vy = (long long)floor(xyz[3 * i + 1] * inv) + kVoxOff;
+        const long long vz = (long long)floor(xyz[3 * i + 2] * inv) + kVoxOff;
+        keys[o_in[i]] = ((uint64_t)vz << (2 * kVoxBits)) | ((uint64_t)vy << kVoxBits) | (uint64_t)vx;
+        vals[o_in[i]] = (uint32_t)i;
+    } else {
+        const size_t o = o_out[i];
+        for (int k = 0; k < 3; ++k) oxyz[3 * o + k] = xyz[3 * i + k];
+        if (nrm)
+            for (int k = 0; k < 3; ++k) onrm[3 * o + k] = nrm[3 * i + k];
+        if (cov)
+            for (int k = 0; k < 9; ++k) ocov[9 * o + k] = cov[9 * i + k];
+    }
+}
+__global__ void k_vox_heads(const uint64_t* __restrict__ keys, int64_t n, uint32_t* __restrict__ flags) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+// one thread per voxel head: sequential sums in double over the voxel's points, which the stable sort left in
+// ascending index order (= the insertion order of the reference's accumulator)
+__global__ void k_vox_reduce(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, int64_t n,
+                             const uint32_t* __restrict__ heads, const uint32_t* __restrict__ vox_id,
+                             const double* __restrict__ xyz, const double* __restrict__ nrm, const double* __restrict__ cov,
+                             int64_t base, double* __restrict__ oxyz, double* __restrict__ onrm, double* __restrict__ ocov) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n || !heads[i]) return;
+    const uint64_t key = keys[i];
+    double p[3] = {0, 0, 0}, nn[3] = {0, 0, 0}, cc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int cnt = 0;
+    for (int64_t j = i; j < n && keys[j] == key; ++j) {
+        const size_t s = vals[j];
+        p[0] += xyz[3 * s];
+        p[1] += xyz[3 * s + 1];
+        p[2] += xyz[3 * s + 2];
+        if (nrm) {
+            const double a = nrm[3 * s], b = nrm[3 * s + 1], c = nrm[3 * s + 2];
+            if (!(a != a) && !(b != b) && !(c != c)) {
+                nn[0] += a;
+                nn[1] += b;
+                nn[2] += c;
+            }
+        }
+        if (cov)
+            for (int k = 0; k < 9; ++k) cc[k] += cov[9 * s + k];
+        ++cnt;
+    }
+    const size_t o = (size_t)base + vox_id[i];
+    const double dc = (double)cnt;
+    for (int k = 0; k < 3; ++k) oxyz[3 * o + k] = p[k] / dc;
+    if (nrm) {
+        double a[3] = {nn[0] / dc, nn[1] / dc, nn[2] / dc};
+        double u = a[0] * a[0];
+        double v = a[1] * a[1];
+        double z2 = u + v;
+        u = a[2] * a[2];
+        z2 = z2 + u;
+        if (z2 > 0.0) {   // Eigen normalized(): the zero vector stays zero
+            const double r = sqrt(z2);
+            a[0] = a[0] / r;
+            a[1] = a[1] / r;
+            a[2] = a[2] / r;
+        }
+        for (int k = 0; k < 3; ++k) onrm[3 * o + k] = a[k];
+    }
+    if (cov)
+        for (int k = 0; k < 9; ++k) ocov[9 * o + k] = cc[k] / dc;
+}
+
 // ---- R8x first-iteration analysis (ICP.cpp:2187-2444): matched pairs -> data frame, centre, alignment sums ----
 // Vectors in fp32 with one rounding per operation (numeric contract), sums in fp64.
 __device__ __forceinline__ float3 xicp_to_data_frame_point(const float* Trd, const float3 p) {
@@ -2197,6 +2289,7 @@ struct reg_handle {
     DevBuf i_xicp;                 // XicpState (R8x first-iteration analysis)
     DevBuf c_in_xyz, c_in_nrm, c_in_cov, c_flags, c_offs, c_xyz, c_nrm, c_cov, c_idx;   // reg_set_target_f64
     int64_t crop_kept = 0;
+    DevBuf v_fout, v_oout, v_oxyz, v_onrm, v_ocov;   // reg_voxelize_within_volume
     bool xicp_pending = false;     // the next generic iteration is followed by the analysis kernels
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_iter = nullptr;
     bool iter_copy_pending = false;
@@ -2352,7 +2445,7 @@ void reg_destroy(reg_handle* h) {
     if (h->normals_ws) reg_destroy(h->normals_ws);
     h->n_out.release();
     h->i_xicp.release();
-    for (DevBuf* b : {&h->c_in_xyz, &h->c_in_nrm, &h->c_in_cov, &h->c_flags, &h->c_offs, &h->c_xyz, &h->c_nrm, &h->c_cov, &h->c_idx}) b->release();
+    for (DevBuf* b : {&h->c_in_xyz, &h->c_in_nrm, &h->c_in_cov, &h->c_flags, &h->c_offs, &h->c_xyz, &h->c_nrm, &h->c_cov, &h->c_idx, &h->v_fout, &h->v_oout, &h->v_oxyz, &h->v_onrm, &h->v_ocov}) b->release();
     h->n_eig.release();
     h->n_cov.release();
     h->n_ids.release();
@@ -2820,6 +2913,140 @@ reg_status reg_get_target_source_indices(reg_handle* h, int32_t* idx) {
     HIPCHK(h, hipSetDevice(h->prm.device));
     HIPCHK(h, hipMemcpyAsync(idx, h->c_idx.p, (size_t)h->crop_kept * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    return REG_OK;
+}
+
+reg_status reg_voxelize_within_volume(reg_handle* h, const double* xyz, const double* normals, const double* covs, int64_t m,
+                                      int on_device, const reg_crop* volume, double voxel_size, double* out_xyz,
+                                      double* out_normals, double* out_covs, int64_t* n_out, int64_t* n_outside) {
+    if (!h) return REG_BAD_ARGUMENT;
+    if (!h->device_ok) return REG_DEVICE_ERROR;
+    if (n_out) *n_out = 0;
+    if (n_outside) *n_outside = 0;
+    if (m < 0 || m > 0x7fffffffLL || (m > 0 && (!xyz || !out_xyz)) || (normals && !out_normals) || (covs && !out_covs))
+        return REG_BAD_ARGUMENT;
+    if (m == 0) return REG_OK;
+    CropCfg c;
+    std::memset(&c, 0, sizeof(c));
+    if (volume) {
+        if (volume->type < REG_CROP_NONE || volume->type > REG_CROP_CYLINDER) return REG_BAD_ARGUMENT;
+        c.type = volume->type;
+        c.cx = volume->center[0];
+        c.cy = volume->center[1];
+        c.cz = volume->center[2];
+        c.rmin = volume->radius_min;
+        c.rmax = volume->radius_max;
+        c.zmin = volume->min_z;
+        c.zmax = volume->max_z;
+    }
+    HIPCHK(h, hipSetDevice(h->prm.device));
+    const hipMemcpyKind in_kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    const hipMemcpyKind out_kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (!(voxel_size > 0.0)) {   // helpers.cpp:121-124: nothing to do
+        HIPCHK(h, hipMemcpyAsync(out_xyz, xyz, (size_t)m * 24, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToHost, h->stream));
+        if (normals) HIPCHK(h, hipMemcpyAsync(out_normals, normals, (size_t)m * 24, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToHost, h->stream));
+        if (covs) HIPCHK(h, hipMemcpyAsync(out_covs, covs, (size_t)m * 72, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (n_out) *n_out = m;
+        if (n_outside) *n_outside = m;
+        return REG_OK;
+    }
+    const double *d_xyz = xyz, *d_nrm = normals, *d_cov = covs;
+    double *d_oxyz = out_xyz, *d_onrm = out_normals, *d_ocov = out_covs;
+    if (!on_device) {
+        HIPCHK(h, h->c_in_xyz.reserve((size_t)m * 24));
+        HIPCHK(h, hipMemcpyAsync(h->c_in_xyz.p, xyz, (size_t)m * 24, in_kind, h->stream));
+        d_xyz = h->c_in_xyz.as<double>();
+        HIPCHK(h, h->v_oxyz.reserve((size_t)m * 24));
+        d_oxyz = h->v_oxyz.as<double>();
+        if (normals) {
+            HIPCHK(h, h->c_in_nrm.reserve((size_t)m * 24));
+            HIPCHK(h, hipMemcpyAsync(h->c_in_nrm.p, normals, (size_t)m * 24, in_kind, h->stream));
+            d_nrm = h->c_in_nrm.as<double>();
+            HIPCHK(h, h->v_onrm.reserve((size_t)m * 24));
+            d_onrm = h->v_onrm.as<double>();
+        }
+        if (covs) {
+            HIPCHK(h, h->c_in_cov.reserve((size_t)m * 72));
+            HIPCHK(h, hipMemcpyAsync(h->c_in_cov.p, covs, (size_t)m * 72, in_kind, h->stream));
+            d_cov = h->c_in_cov.as<double>();
+            HIPCHK(h, h->v_ocov.reserve((size_t)m * 72));
+            d_ocov = h->v_ocov.as<double>();
+        }
+    }
+    const double inv = 1.0 / voxel_size;   // fromVoxelSize (VoxelHashMap.hpp:43-45)
+    HIPCHK(h, h->c_flags.reserve((size_t)m * 4));
+    HIPCHK(h, h->c_offs.reserve((size_t)m * 4));
+    HIPCHK(h, h->v_fout.reserve((size_t)m * 4));
+    HIPCHK(h, h->v_oout.reserve((size_t)m * 4));
+    HIPCHK(h, h->t_misc.reserve(256));
+    HIPCHK(h, hipMemsetAsync(h->t_misc.p, 0, 4, h->stream));
+    k_vox_classify<<<grid_for(m), 256, 0, h->stream>>>(d_xyz, m, c, inv, h->c_flags.as<uint32_t>(), h->v_fout.as<uint32_t>(),
+                                                       h->t_misc.as<uint32_t>());
+    size_t tb = 0;
+    HIPCHK(h, rocprim::exclusive_scan(nullptr, tb, h->c_flags.as<uint32_t>(), h->c_offs.as<uint32_t>(), 0u, (size_t)m,
+                                      rocprim::plus<uint32_t>(), h->stream));
+    HIPCHK(h, h->t_tmp.reserve(tb));
+    HIPCHK(h, rocprim::exclusive_scan(h->t_tmp.p, tb, h->c_flags.as<uint32_t>(), h->c_offs.as<uint32_t>(), 0u, (size_t)m,
+                                      rocprim::plus<uint32_t>(), h->stream));
+    HIPCHK(h, rocprim::exclusive_scan(h->t_tmp.p, tb, h->v_fout.as<uint32_t>(), h->v_oout.as<uint32_t>(), 0u, (size_t)m,
+                                      rocprim::plus<uint32_t>(), h->stream));
+    uint32_t tail[3] = {0, 0, 0};
+    HIPCHK(h, hipMemcpyAsync(&tail[0], h->c_offs.as<uint32_t>() + (m - 1), 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(&tail[1], h->c_flags.as<uint32_t>() + (m - 1), 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(&tail[2], h->t_misc.p, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (tail[2]) {
+        h->err = "voxel_size too small for the extent of the cloud (voxel index exceeds 2^20)";
+        return REG_BAD_ARGUMENT;
+    }
+    const int64_t n_in = (int64_t)tail[0] + tail[1], n_outs = m - n_in;
+    int64_t n_vox = 0;
+    HIPCHK(h, h->t_keys.reserve((size_t)std::max<int64_t>(n_in, 1) * 8));
+    HIPCHK(h, h->t_keys2.reserve((size_t)std::max<int64_t>(n_in, 1) * 8));
+    HIPCHK(h, h->t_vals.reserve((size_t)std::max<int64_t>(n_in, 1) * 4));
+    HIPCHK(h, h->t_vals2.reserve((size_t)std::max<int64_t>(n_in, 1) * 4));
+    k_vox_scatter<<<grid_for(m), 256, 0, h->stream>>>(d_xyz, d_nrm, d_cov, m, inv, h->c_flags.as<uint32_t>(),
+                                                      h->c_offs.as<uint32_t>(), h->v_oout.as<uint32_t>(),
+                                                      h->t_keys.as<uint64_t>(), h->t_vals.as<uint32_t>(), d_oxyz, d_onrm,
+                                                      d_ocov);
+    if (n_in > 0) {
+        size_t sb = 0;
+        HIPCHK(h, rocprim::radix_sort_pairs(nullptr, sb, h->t_keys.as<uint64_t>(), h->t_keys2.as<uint64_t>(),
+                                            h->t_vals.as<uint32_t>(), h->t_vals2.as<uint32_t>(), (size_t)n_in, 0,
+                                            3 * kVoxBits, h->stream));
+        HIPCHK(h, h->t_tmp.reserve(sb));
+        HIPCHK(h, rocprim::radix_sort_pairs(h->t_tmp.p, sb, h->t_keys.as<uint64_t>(), h->t_keys2.as<uint64_t>(),
+                                            h->t_vals.as<uint32_t>(), h->t_vals2.as<uint32_t>(), (size_t)n_in, 0,
+                                            3 * kVoxBits, h->stream));
+        HIPCHK(h, h->t_flags.reserve((size_t)n_in * 4));
+        HIPCHK(h, h->t_scan.reserve((size_t)n_in * 4));
+        k_vox_heads<<<grid_for(n_in), 256, 0, h->stream>>>(h->t_keys2.as<uint64_t>(), n_in, h->t_flags.as<uint32_t>());
+        size_t eb = 0;
+        HIPCHK(h, rocprim::exclusive_scan(nullptr, eb, h->t_flags.as<uint32_t>(), h->t_scan.as<uint32_t>(), 0u, (size_t)n_in,
+                                          rocprim::plus<uint32_t>(), h->stream));
+        HIPCHK(h, h->t_tmp.reserve(eb));
+        HIPCHK(h, rocprim::exclusive_scan(h->t_tmp.p, eb, h->t_flags.as<uint32_t>(), h->t_scan.as<uint32_t>(), 0u, (size_t)n_in,
+                                          rocprim::plus<uint32_t>(), h->stream));
+        uint32_t lv[2] = {0, 0};
+        HIPCHK(h, hipMemcpyAsync(&lv[0], h->t_scan.as<uint32_t>() + (n_in - 1), 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(&lv[1], h->t_flags.as<uint32_t>() + (n_in - 1), 4, hipMemcpyDeviceToHost, h->stream));
+        k_vox_reduce<<<grid_for(n_in), 256, 0, h->stream>>>(h->t_keys2.as<uint64_t>(), h->t_vals2.as<uint32_t>(), n_in,
+                                                            h->t_flags.as<uint32_t>(), h->t_scan.as<uint32_t>(), d_xyz, d_nrm,
+                                                            d_cov, n_outs, d_oxyz, d_onrm, d_ocov);
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        n_vox = (int64_t)lv[0] + lv[1];
+    }
+    const int64_t total = n_outs + n_vox;
+    if (!on_device) {
+        HIPCHK(h, hipMemcpyAsync(out_xyz, d_oxyz, (size_t)total * 24, out_kind, h->stream));
+        if (normals) HIPCHK(h, hipMemcpyAsync(out_normals, d_onrm, (size_t)total * 24, out_kind, h->stream));
+        if (covs) HIPCHK(h, hipMemcpyAsync(out_covs, d_ocov, (size_t)total * 72, out_kind, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    if (n_out) *n_out = total;
+    if (n_outside) *n_outside = n_outs;
     return REG_OK;
 }
 

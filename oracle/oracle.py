@@ -296,3 +296,43 @@ def crop_mask(xyz, crop_type, center=(0.0, 0.0, 0.0), radius_min=0.0, radius_max
     if crop_type == 2:
         return r >= radius_min
     return (r <= radius_max) & (r >= radius_min)
+
+
+def voxelize_within_volume(xyz, voxel_size, inside_mask, normals=None, covs=None):
+    """voxelizeWithinCroppingVolume (open3d_slam/src/helpers.cpp:117-192) restated with a plain dict: points outside the
+    volume pass through in order; inside points are accumulated per voxel index floor(p * (1/voxel)) (VoxelHashMap.hpp:
+    43-51) in index order in float64 (AccumulatedPoint, helpers.cpp:30-72).  Voxels are emitted in ascending (z, y, x)
+    index (the reference's unordered_map order is unspecified).  Returns (xyz, normals, covs, n_outside)."""
+    p = np.asarray(xyz, np.float64)
+    nr = np.asarray(normals, np.float64) if normals is not None else None
+    cv = np.asarray(covs, np.float64).reshape(-1, 9) if covs is not None else None
+    if not voxel_size > 0:
+        return p.copy(), nr, cv, p.shape[0]
+    inv = 1.0 / float(voxel_size)
+    out_idx = np.nonzero(~inside_mask)[0]
+    acc = {}
+    for i in np.nonzero(inside_mask)[0]:
+        key = (int(np.floor(p[i, 2] * inv)), int(np.floor(p[i, 1] * inv)), int(np.floor(p[i, 0] * inv)))
+        a = acc.get(key)
+        if a is None:
+            a = acc[key] = [np.zeros(3), np.zeros(3), np.zeros(9), 0]
+        a[0] = a[0] + p[i]
+        if nr is not None and not np.any(np.isnan(nr[i])):
+            a[1] = a[1] + nr[i]
+        if cv is not None:
+            a[2] = a[2] + cv[i]
+        a[3] += 1
+    keys = sorted(acc)
+    vp = np.array([acc[k][0] / float(acc[k][3]) for k in keys]).reshape(-1, 3)
+    ox = np.concatenate([p[out_idx], vp])
+    on = oc = None
+    if nr is not None:
+        vn = []
+        for k in keys:
+            a = acc[k][1] / float(acc[k][3])
+            z2 = (a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]
+            vn.append(a / np.sqrt(z2) if z2 > 0 else a)
+        on = np.concatenate([nr[out_idx], np.array(vn).reshape(-1, 3)])
+    if cv is not None:
+        oc = np.concatenate([cv[out_idx], np.array([acc[k][2] / float(acc[k][3]) for k in keys]).reshape(-1, 9)])
+    return ox, on, oc, out_idx.size

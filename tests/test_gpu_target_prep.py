@@ -87,3 +87,39 @@ def test_gicp_covariances_travel_through_the_crop():
     ref.set_source(sc.src_xyz, None, sc.src_cov)
     T2, _ = ref.register(np.eye(4))
     assert np.array_equal(T, T2)
+
+
+@pytest.mark.parametrize("with_attrs", [True, False])
+def test_voxelize_within_volume_is_bit_exact(with_attrs):
+    """Map maintenance half of the row: voxelizeWithinCroppingVolume (helpers.cpp:117-192).  Integer bucketing + fp64
+    sums in index order: the device result equals the restatement bit for bit (voxels compared in ascending index)."""
+    rng = np.random.default_rng(11)
+    sc = synth.make_scene(1000, 60000, seed=12)
+    xyz = sc.tgt_xyz.astype(np.float64) + rng.normal(scale=1e-7, size=sc.tgt_xyz.shape)
+    # a second, slightly shifted copy: what the map looks like right after `mapCloud_ += transformedScan`
+    xyz = np.concatenate([xyz, xyz[:20000] + rng.normal(scale=0.02, size=(20000, 3))])
+    nrm = cov = None
+    if with_attrs:
+        nrm = np.concatenate([sc.tgt_nrm, sc.tgt_nrm[:20000]]).astype(np.float64)
+        nrm[5] = np.nan                                                 # NaN normals are skipped (helpers.cpp:35)
+        C6 = np.concatenate([sc.tgt_cov, sc.tgt_cov[:20000]]).astype(np.float64)
+        cov = np.stack([C6[:, 0], C6[:, 1], C6[:, 2], C6[:, 1], C6[:, 3], C6[:, 4], C6[:, 2], C6[:, 4], C6[:, 5]], axis=1)
+    vol = dict(type=capi.CROP_MAX_RADIUS, center=(1.0, 0.5, 0.0), radius_max=12.0)
+    reg = capi.Registration(capi.default_params())
+    ox, on, oc, n_outside = reg.voxelize_within_volume(xyz, 0.15, vol, nrm, cov)
+    mask = orc.crop_mask(xyz, 1, center=(1.0, 0.5, 0.0), radius_max=12.0)
+    rx, rn, rc, r_out = orc.voxelize_within_volume(xyz, 0.15, mask, nrm, cov)
+    assert n_outside == r_out and ox.shape == rx.shape and ox.shape[0] < xyz.shape[0]
+    assert np.array_equal(ox, rx)
+    if with_attrs:
+        assert np.array_equal(on, rn, equal_nan=True) and np.array_equal(oc, rc)
+        assert np.allclose(np.linalg.norm(on[n_outside:], axis=1), 1.0, atol=1e-12)
+    # voxel_size <= 0: the cloud passes through (helpers.cpp:121-124); negative coordinates bucket with floor()
+    px, _, _, po = reg.voxelize_within_volume(xyz[:100], 0.0, vol)
+    assert np.array_equal(px, xyz[:100]) and po == 100
+    neg = np.array([[-0.05, -0.05, -0.05], [-0.01, -0.09, -0.02], [0.01, 0.01, 0.01], [5.0, 5.0, 5.0]])
+    vx, _, _, vo = reg.voxelize_within_volume(neg, 0.1, dict(type=capi.CROP_MAX_RADIUS, center=(0, 0, 0), radius_max=1.0))
+    assert vo == 1 and vx.shape[0] == 3 and np.array_equal(vx[0], neg[3])
+    assert np.array_equal(vx[1], (neg[0] + neg[1]) / 2.0) and np.array_equal(vx[2], neg[2])
+    with pytest.raises(capi.RegError):                                  # voxel index overflow fails loudly
+        reg.voxelize_within_volume(np.array([[1e9, 0.0, 0.0]]), 1e-3, None)

@@ -36,3 +36,29 @@ t0 = time.perf_counter()
 reg.set_target(x32, n32)
 t_up = time.perf_counter() - t0
 print(f"host crop+cast (numpy, 1 thread): {t_cpu*1e3:.1f} ms; upload + build of the fp32 patch: {t_up*1e3:.1f} ms")
+
+# map maintenance: voxelise the map inside the volume (helpers.cpp:117-192), cloud resident in HBM
+import ctypes as C
+d_ox = torch.empty_like(d_x)
+d_on = torch.empty_like(d_n)
+c = reg._crop_struct(crop)
+n_out, n_outside = C.c_int64(0), C.c_int64(0)
+
+
+def vox():
+    reg._check(reg._lib.reg_voxelize_within_volume(reg._h, C.c_void_p(d_x.data_ptr()), C.c_void_p(d_n.data_ptr()), None,
+                                                   xyz64.shape[0], 1, C.byref(c), 0.1, C.c_void_p(d_ox.data_ptr()),
+                                                   C.c_void_p(d_on.data_ptr()), None, C.byref(n_out), C.byref(n_outside)))
+
+
+for _ in range(2):
+    vox()
+t0 = time.perf_counter()
+for _ in range(reps):
+    vox()
+dt = (time.perf_counter() - t0) / reps
+print(f"GPU  voxelize-within-volume (0.1 m): {xyz64.shape[0]} points -> {n_out.value} ({n_outside.value} outside): {dt*1e3:.2f} ms")
+sub = 400000
+t0 = time.perf_counter()
+orc.voxelize_within_volume(xyz64[:sub], 0.1, orc.crop_mask(xyz64[:sub], 1, radius_max=15.0), nrm64[:sub])
+print(f"host restatement (python dict) on {sub} points: {(time.perf_counter()-t0)*1e3:.0f} ms")
