@@ -1,0 +1,602 @@
+// host_loop.hpp -- reading preparation, iteration state, kernel enqueue helpers, reg_register and the other single-GPU entry points
+// Part of the single translation unit reg_core.hip (included there, in this order; not a standalone header).
+#pragma once
+
+// =================================================================================================
+// iteration driver (host)
+// =================================================================================================
+
+static reg_status check_ready(reg_handle* h, bool need_prepared) {
+    if (!h) return REG_BAD_ARGUMENT;
+    if (!h->device_ok) return REG_DEVICE_ERROR;
+    if (h->m == 0) {
+        h->err = "no reference set (reg_set_target)";
+        return REG_NOT_CONFIGURED;
+    }
+    if (h->n == 0) {
+        h->err = "no reading set (reg_set_source)";
+        return REG_NOT_CONFIGURED;
+    }
+    if (need_prepared && !h->prepared) {
+        h->err = "reg_prepare has not been called for this reading";
+        return REG_NOT_CONFIGURED;
+    }
+    return REG_OK;
+}
+
+// R2
+static reg_status prepare_rowmajor(reg_handle* h, const float* T_init_row, const float* c_override = nullptr) {
+    reg_status s = check_ready(h, false);
+    if (s != REG_OK) return s;
+    if (!m4_is_finite(T_init_row)) {
+        h->err = "initial transformation contains non-finite values";
+        return REG_BAD_TRANSFORM;
+    }
+    const bool ptrace = getenv("O3D_TRACE") != nullptr;
+    const auto pt0 = std::chrono::steady_clock::now();
+    auto pmark = [&](const char* what) {
+        if (ptrace) fprintf(stderr, "[o3dreg] prepare %-18s t=%.1fus\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - pt0).count());
+    };
+    HIPCHK(h, hipSetDevice(h->prm.device));
+    std::memcpy(h->T_init, T_init_row, 64);
+    const int64_t n = h->n;
+    const bool p2pl = h->prm.cost == REG_COST_P2PL;
+    // centroid sums -> (device) centroid + T0; the host copy arrives later through the pinned staging buffer and is
+    // only needed for the final composition (R10), so nothing here waits for the device
+    HIPCHK(h, h->s_misc.reserve(256));
+    HIPCHK(h, h->s_prep.reserve(sizeof(PrepState)));
+    if (p2pl && !c_override) {
+        HIPCHK(h, hipMemsetAsync(h->s_misc.p, 0, 3 * sizeof(unsigned long long), h->stream));
+        const int blocks = (int)std::min<int64_t>(1024, (n + 255) / 256);
+        k_centroid_sums<<<blocks, 256, 0, h->stream>>>(h->s_raw.as<float>(), h->s_stride, n,
+                                                       h->s_misc.as<unsigned long long>());
+    }
+    pmark("centroid");
+    Xf4 Ti;
+    std::memcpy(Ti.m, T_init_row, 64);
+    k_make_T0<<<1, 64, 0, h->stream>>>(h->s_misc.as<unsigned long long>(), n,
+                                       make_float3(h->c_ref[0], h->c_ref[1], h->c_ref[2]), Ti, p2pl ? 1 : 0,
+                                       c_override ? 1 : 0,
+                                       c_override ? make_float3(c_override[0], c_override[1], c_override[2])
+                                                  : make_float3(0.f, 0.f, 0.f),
+                                       h->s_prep.as<PrepState>(), h->d_prep_host);
+    h->prep_pending = true;
+    pmark("T0+copy");
+    const PrepState* ps = h->s_prep.as<PrepState>();
+    k_prepare_source<<<grid_for(n), 256, 0, h->stream>>>(
+        h->s_raw.as<float>(), h->s_stride, (p2pl && h->has_snrm) ? h->s_nrm_raw.as<float>() : nullptr, h->s_nstride, n, ps,
+        p2pl ? 1 : 0, h->perm, h->s_xyz.as<float4>(), (p2pl && h->has_snrm) ? h->s_nrm.as<float4>() : nullptr,
+        h->i_hint.as<uint8_t>(), h->i_hist.as<uint32_t>(), h->i_acc.as<double>(), kAccRows * kSums);
+    if (!p2pl)
+        k_pack_cov<<<grid_for(n), 256, 0, h->stream>>>(h->s_cov_raw.as<float>(), n, h->perm, h->s_cov.as<float4>());
+    pmark("prepare_source");
+    HIPCHK(h, hipGetLastError());
+    h->prepared = true;
+    h->have_match = false;
+    return REG_OK;
+}
+
+// ---- iteration state ---------------------------------------------------------------------------------
+
+// (Re)initialise the device-side iteration state: pose T (row-major), mode and checker configuration.
+static reg_status init_iter_state(reg_handle* h, const float* T_row, int update) {
+    IterState* st = h->h_iter;
+    // the pinned staging copy may still be in flight from the previous call: wait for THAT copy only (an event
+    // recorded right behind it), not for everything else enqueued on the stream
+    if (h->iter_copy_pending) HIPCHK(h, hipEventSynchronize(h->ev_iter));
+    std::memset(st, 0, sizeof(IterState));
+    for (int i = 0; i < 16; ++i) {
+        st->T[i] = T_row[i];
+        st->Td[i] = (double)T_row[i];
+    }
+    st->chk = Checkers();
+    st->chk.max_iter = h->prm.max_iter;
+    st->chk.min_diff_rot = h->prm.min_diff_rot;
+    st->chk.min_diff_trans = h->prm.min_diff_trans;
+    st->chk.smooth_len = h->prm.smooth_len;
+    st->chk.init(T_row);
+    st->cost = h->prm.cost;
+    st->fixed_iters = h->prm.fixed_iters;
+    st->max_iter = h->prm.max_iter;
+    st->update = update;
+    st->gicp_rot_eps = h->prm.gicp_rot_eps;
+    st->gicp_trans_eps = h->prm.gicp_trans_eps;
+    st->band_lo = st->band_hi = INFINITY;
+    st->limit_last = st->limit_prev = INFINITY;
+    st->use_trim = (h->prm.cost == REG_COST_P2PL && h->prm.use_trimmed) ? 1 : 0;
+    st->trim_ratio = h->prm.trim_ratio;
+    st->band_cap = kBandCap;
+    st->debug_narrow_band = (h->prm.debug_flags & 8) ? 1 : 0;
+    h->xicp_pending = false;
+    for (int k = 0; k < 6; ++k) st->xicp_flags[k] = 1;
+    if (h->prm.use_xicp && h->prm.cost == REG_COST_P2PL && update) {
+        HIPCHK(h, h->i_xicp.reserve(sizeof(XicpState)));
+        st->xicp_stage = 1;
+        st->xicp_enough = h->prm.xicp_enough;
+        st->xicp_insufficient = h->prm.xicp_insufficient;
+        st->xicp_cos_min = (float)std::cos((double)h->prm.xicp_min_angle_deg * 3.14159265358979323846 / 180.0);
+        st->xicp_cos_strong = (float)std::cos((double)h->prm.xicp_strong_angle_deg * 3.14159265358979323846 / 180.0);
+        // T_refMean_dataIn = T_refIn_refMean^-1 * T_init (ICP.cpp:1067): the frame change of the analysis
+        float A[16], Trd[16];
+        m4_identity(A);
+        for (int k = 0; k < 3; ++k) A[4 * k + 3] = -h->c_ref[k];
+        m4_mul(A, h->T_init, Trd);
+        for (int k = 0; k < 12; ++k) st->xicp_Trd[k] = Trd[k];
+        h->xicp_pending = true;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->i_iter.p, st, sizeof(IterState), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipEventRecord(h->ev_iter, h->stream));
+    h->iter_copy_pending = true;
+    return REG_OK;
+}
+
+// R3+R4.  Buffer hygiene of the trimmed-quantile histograms needs no memset launches: the match kernel
+// zeroes hist2, the level-2 select kernel zeroes hist0, the linearize kernel zeroes hist1.
+static void prof_mark(reg_handle* h, int kind, bool start) {
+    if (!h->profiling) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, h->stream);
+    h->prof_ev.push_back(e);
+    if (start) h->prof_kind.push_back(kind);
+}
+
+static reg_status enqueue_match(reg_handle* h, bool zero_hist = false) {
+    const bool trim = h->prm.cost == REG_COST_P2PL && h->prm.use_trimmed;
+    if (trim && zero_hist) HIPCHK(h, hipMemsetAsync(h->i_hist.p, 0, 3 * 2048 * 4, h->stream));
+    const bool fused_hist = h->prm.match_variant == 3;
+    uint32_t* hist0 = (trim && fused_hist) ? h->i_hist.as<uint32_t>() : nullptr;
+    uint32_t* hist2 = trim ? h->i_hist.as<uint32_t>() + 4096 : nullptr;
+    const IterState* it = h->i_iter.as<IterState>();
+    prof_mark(h, 0, true);
+    if (h->prm.match_variant == 1) {
+        k_match<<<h->n_blocks, 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->n, it, h->grid, h->i_pos.as<int>(),
+                                                    h->i_d2.as<float>(), hist0, hist2, h->shift0);
+    } else {
+        uint8_t* hint = h->prm.match_variant == 2 ? nullptr : h->i_hint.as<uint8_t>();
+        if (h->prm.lanes_per_point == 4) {
+            const int blocks = grid_for(h->n * 4);
+            k_match_g8<4><<<8 * ((blocks + 7) / 8), 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->n, it, h->grid,
+                                                                          h->i_pos.as<int>(), h->i_d2.as<float>(), hist0,
+                                                                          hist2, hint, h->shift0, h->prm.debug_flags, blocks);
+        } else if (h->prm.lanes_per_point == 2) {
+            const int blocks = grid_for(h->n * 2);
+            k_match_g8<2><<<8 * ((blocks + 7) / 8), 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->n, it, h->grid,
+                                                                          h->i_pos.as<int>(), h->i_d2.as<float>(), hist0,
+                                                                          hist2, hint, h->shift0, h->prm.debug_flags, blocks);
+        } else {
+            const int blocks = grid_for(h->n * 8);
+            k_match_g8<8><<<8 * ((blocks + 7) / 8), 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->n, it, h->grid,
+                                                                          h->i_pos.as<int>(), h->i_d2.as<float>(), hist0,
+                                                                          hist2, hint, h->shift0, h->prm.debug_flags, blocks);
+        }
+    }
+    prof_mark(h, 0, false);
+    h->have_match = true;
+    return REG_OK;
+}
+
+// exact k-th smallest finite d2: level 0 and 1 histograms here, the last level inside the linearize kernel
+static reg_status enqueue_select(reg_handle* h) {
+    uint32_t* hist0 = h->i_hist.as<uint32_t>();
+    SelectState* st = h->i_state.as<SelectState>();
+    const IterState* it = h->i_iter.as<IterState>();
+    const int hb = std::min(h->n_blocks, 128);
+    const float ratio = h->prm.trim_ratio;
+    if (h->prm.match_variant != 3)
+        k_hist_level0<<<hb, 256, 0, h->stream>>>(h->i_d2.as<float>(), h->n, h->shift0, hist0, it);
+    k_select_level<<<hb, 256, 0, h->stream>>>(h->i_d2.as<float>(), h->n, 1, h->shift0, ratio, hist0, hist0 + 2048,
+                                              nullptr, st, it);
+    k_select_level<<<hb, 256, 0, h->stream>>>(h->i_d2.as<float>(), h->n, 2, h->shift0, ratio, hist0 + 2048,
+                                              hist0 + 4096, hist0, st, it);
+    return REG_OK;
+}
+
+static FilterCfg make_filter_cfg(const reg_handle* h, int trim_mode);
+
+static reg_status enqueue_linearize(reg_handle* h, bool want_w, bool limit_from_state = false) {
+    float* w = want_w ? h->i_w.as<float>() : nullptr;
+    const IterState* it = h->i_iter.as<IterState>();
+    if (h->prm.cost == REG_COST_P2PL) {
+        const FilterCfg f = make_filter_cfg(h, h->prm.use_trimmed ? (limit_from_state ? 1 : 2) : 0);
+        k_linearize_p2pl<<<h->n_blocks, 256, 0, h->stream>>>(
+            h->s_xyz.as<float4>(), h->has_snrm ? h->s_nrm.as<float4>() : nullptr, h->n, it, h->i_pos.as<int>(),
+            h->i_d2.as<float>(), h->t_pts.as<float4>(), h->t_nrm.as<float4>(), f, h->i_state.as<SelectState>(),
+            h->i_hist.as<uint32_t>() + 4096, h->i_hist.as<uint32_t>() + 2048, h->shift0, w,
+            h->i_partials.as<double>());
+    } else {
+        k_linearize_gicp<<<h->n_blocks, 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->s_cov.as<float4>(), h->n, it,
+                                                             h->i_pos.as<int>(), h->i_d2.as<float>(),
+                                                             h->t_pts.as<float4>(), h->t_cov.as<float4>(), w,
+                                                             h->i_partials.as<double>());
+    }
+    ++h->seq;
+    k_reduce_update<<<1, 1024, 0, h->stream>>>(h->i_partials.as<double>(), h->n_blocks, h->i_iter.as<IterState>(),
+                                               h->d_mirror, h->seq, 0, nullptr, nullptr,
+                                               h->prm.cost == REG_COST_P2PL ? h->i_state.as<SelectState>() : nullptr,
+                                               nullptr, 0, 0, h->i_xicp.as<XicpState>());
+    if (h->xicp_pending) {
+        // R8x, first iteration: collect the information sums on the matched pairs, then decide + solve + update
+        h->xicp_pending = false;
+        const int blocks = (int)std::min<int64_t>(512, (h->n + 255) / 256);
+        k_xicp_center<<<blocks, 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->n, h->i_iter.as<IterState>(),
+                                                     h->i_pos.as<int>(), h->i_w.as<float>(), h->i_xicp.as<XicpState>());
+        k_xicp_detect<<<blocks, 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->n, h->i_iter.as<IterState>(),
+                                                     h->i_pos.as<int>(), h->i_w.as<float>(), h->t_nrm.as<float4>(),
+                                                     h->i_xicp.as<XicpState>());
+        k_reduce_update<<<1, 1024, 0, h->stream>>>(nullptr, 0, h->i_iter.as<IterState>(), h->d_mirror, h->seq, 2, nullptr,
+                                                   nullptr, nullptr, nullptr, 0, 0, h->i_xicp.as<XicpState>());
+    }
+    return REG_OK;
+}
+
+static FilterCfg make_filter_cfg(const reg_handle* h, int trim_mode) {
+    FilterCfg f;
+    f.use_trim = trim_mode;
+    f.use_normal = h->prm.use_surface_normal;
+    f.use_maxdist = h->prm.use_max_dist_filter;
+    f.debug = h->prm.debug_flags;
+    f.cos_max_angle = std::cos(h->prm.max_normal_angle);  // cosf in T=float (OutlierFiltersImpl.cpp:229)
+    const float md = h->prm.outlier_max_dist;
+    f.outlier_max_d2 = md * md;
+    return f;
+}
+
+// Fused iteration (point-to-plane): search + weights + normal equations in one kernel, band resolution +
+// solve + update in the second.  Two launches per Gauss-Newton iteration.
+template <int G>
+static void launch_fused(reg_handle* h, const FilterCfg& f, float* w, uint8_t* hint) {
+    const int blocks = grid_for(h->n * G);
+    prof_mark(h, 1, true);
+    k_iter_fused<G><<<8 * ((blocks + 7) / 8), 256, 0, h->stream>>>(
+        h->s_xyz.as<float4>(), h->has_snrm ? h->s_nrm.as<float4>() : nullptr, h->n, h->i_iter.as<IterState>(), h->grid,
+        h->t_nrm.as<float4>(), f, h->i_pos.as<int>(), h->i_d2.as<float>(), w, hint, h->i_band.as<float>(), kBandCap,
+        h->i_acc.as<double>(), blocks);
+    prof_mark(h, 1, false);
+    ++h->seq;
+    k_reduce_update<<<1, 1024, 0, h->stream>>>(h->i_acc.as<double>(), blocks, h->i_iter.as<IterState>(), h->d_mirror,
+                                               h->seq, 1, h->i_band.as<float>(), w, nullptr, nullptr, 0, 0, nullptr);
+}
+
+static reg_status enqueue_fused(reg_handle* h, bool want_w) {
+    const FilterCfg f = make_filter_cfg(h, 0);
+    float* w = want_w ? h->i_w.as<float>() : nullptr;
+    uint8_t* hint = h->prm.match_variant == 2 ? nullptr : h->i_hint.as<uint8_t>();
+    if (h->prm.lanes_per_point == 4)
+        launch_fused<4>(h, f, w, hint);
+    else
+        launch_fused<8>(h, f, w, hint);
+    h->have_match = true;
+    return REG_OK;
+}
+
+// One Gauss-Newton iteration worth of kernels (R3-R9), nothing waits on the host.
+static reg_status enqueue_iteration(reg_handle* h, bool want_w) {
+    reg_status s = enqueue_match(h);
+    if (s != REG_OK) return s;
+    if (h->prm.cost == REG_COST_P2PL && h->prm.use_trimmed) {
+        s = enqueue_select(h);
+        if (s != REG_OK) return s;
+    }
+    return enqueue_linearize(h, want_w);
+}
+
+static inline unsigned long long mirror_seq(const reg_handle* h) {
+    return __atomic_load_n(&h->h_mirror->seq, __ATOMIC_ACQUIRE);
+}
+
+// Wait until the update kernel with sequence number `seq` (or a later one) has published its mirror.
+// Polling the mapped word is ~10 us cheaper per wait than hipStreamSynchronize; a stream query every few
+// thousand spins turns a device fault (or an early `done`) into a return instead of a hang.
+static reg_status wait_seq(reg_handle* h, unsigned long long seq) {
+    for (unsigned spins = 0;; ++spins) {
+        if (mirror_seq(h) >= seq) return REG_OK;
+        if ((spins & 0x3fff) == 0x3fff) {
+            hipError_t e = hipStreamQuery(h->stream);
+            if (e == hipSuccess) return REG_OK;  // everything enqueued has run (later iterations were no-ops)
+            if (e != hipErrorNotReady) {
+                h->err = std::string("device fault while waiting for the iteration: ") + hipGetErrorString(e);
+                return REG_DEVICE_ERROR;
+            }
+        }
+    }
+}
+
+// one full pass R3-R7 at T (row-major) without pose update; sums -> h->h_mirror->sums
+static reg_status iterate_once(reg_handle* h, const float* T_row, bool want_w) {
+    reg_status s = init_iter_state(h, T_row, 0);
+    if (s != REG_OK) return s;
+    s = enqueue_iteration(h, want_w);
+    if (s != REG_OK) return s;
+    s = wait_seq(h, h->seq);
+    if (s != REG_OK) return s;
+    HIPCHK(h, hipGetLastError());
+    return REG_OK;
+}
+
+static void sums_to_system(const double* sums, bool p2pl, float* H, float* b) {
+    int k = 0;
+    for (int a = 0; a < 6; ++a)
+        for (int c = a; c < 6; ++c) {
+            const float v = (float)sums[k++];
+            H[6 * a + c] = v;
+            H[6 * c + a] = v;
+        }
+    for (int a = 0; a < 6; ++a) b[a] = p2pl ? -(float)sums[21 + a] : (float)sums[21 + a];
+}
+
+// R10: T = T_refIn_refMean * T_iter * T_refMean_readMean * T_readIn_readMean^-1 (ICP.cpp:1345); GICP: T_iter itself
+static void compose_rowmajor(reg_handle* h, const float* T_iter, float* Tout_row, bool later_kernel_reported = false) {
+    if (h->prep_pending) {
+        // k_make_T0 wrote PrepState into mapped host memory (system-scope fence); it is visible once that kernel has
+        // completed: either a later kernel of the same stream has already reported through the mirror, or wait here
+        if (!later_kernel_reported) (void)hipStreamSynchronize(h->stream);
+        std::memcpy(h->c_read, h->h_prep->c_read, 12);
+        std::memcpy(h->T0, h->h_prep->T0, 64);
+        h->prep_pending = false;
+    }
+    if (h->prm.cost == REG_COST_P2PL) {
+        float A[16], B[16], t1[16], t2[16];
+        m4_identity(A);
+        m4_identity(B);
+        for (int k = 0; k < 3; ++k) {
+            A[4 * k + 3] = h->c_ref[k];
+            B[4 * k + 3] = -h->c_read[k];
+        }
+        m4_mul(A, T_iter, t1);
+        m4_mul(t1, h->T0, t2);
+        m4_mul(t2, B, Tout_row);
+    } else {
+        std::memcpy(Tout_row, T_iter, 64);
+    }
+}
+
+static void fill_result(reg_handle* h, const double* sums, reg_result* res) {
+    res->n_inliers = (int64_t)llround(sums[28]);
+    res->n_matched = (int64_t)llround(sums[29]);
+    res->error = sums[27];
+    res->fitness = h->n > 0 ? sums[28] / (double)h->n : 0.0;
+    res->inlier_rmse = sums[28] > 0 ? std::sqrt(sums[30] / sums[28]) : 0.0;
+    sums_to_system(sums, h->prm.cost == REG_COST_P2PL, res->H_last, res->b_last);
+    res->target_build_ms = h->target_build_ms;
+}
+
+extern "C" {
+
+reg_status reg_prepare(reg_handle* h, const float T_init[16]) {
+    if (!h || !T_init) return REG_BAD_ARGUMENT;
+    float Tr[16];
+    col_to_row(T_init, Tr);
+    return prepare_rowmajor(h, Tr);
+}
+
+reg_status reg_linearize(reg_handle* h, const float T_iter[16], float H[36], float b[6], double* err,
+                         int64_t* n_inliers) {
+    reg_status s = check_ready(h, true);
+    if (s != REG_OK) return s;
+    if (!T_iter) return REG_BAD_ARGUMENT;
+    float Tr[16];
+    col_to_row(T_iter, Tr);
+    if (!m4_is_finite(Tr)) return REG_BAD_TRANSFORM;
+    HIPCHK(h, hipSetDevice(h->prm.device));
+    s = iterate_once(h, Tr, true);
+    if (s != REG_OK) return s;
+    const double* sums = h->h_mirror->sums;
+    if (H && b) sums_to_system(sums, h->prm.cost == REG_COST_P2PL, H, b);
+    if (err) *err = sums[27];
+    if (n_inliers) *n_inliers = (int64_t)llround(sums[28]);
+    if (sums[28] == 0.0) {
+        h->err = "ErrorMinimizer: no point to minimize";
+        return REG_NO_CORRESPONDENCES;
+    }
+    return REG_OK;
+}
+
+// == ICP::compute on the prepared reading.  The whole while(iterate) loop (ICP.cpp:1027-1311) runs on the
+// device; the host only keeps the queue fed.  fixed_iters > 0: every iteration is enqueued at once.
+// Checker mode: the host stays at most kAhead iterations ahead of what it has seen complete, so at most
+// kAhead enqueued iterations turn into no-ops after convergence.
+reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], reg_result* res) {
+    if (!h || !T_init || !T_out) return REG_BAD_ARGUMENT;
+    reg_result local;
+    if (!res) res = &local;
+    std::memset(res, 0, sizeof(*res));
+    std::memcpy(T_out, T_init, 64);
+    float Ti[16];
+    col_to_row(T_init, Ti);
+    const auto t_reg0 = std::chrono::steady_clock::now();
+    auto rmark = [&](const char* what) {
+        if (getenv("O3D_TRACE"))
+            fprintf(stderr, "[o3dreg] register %-14s t=%.1fus\n", what,
+                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_reg0).count());
+    };
+    reg_status s = prepare_rowmajor(h, Ti);
+    if (s != REG_OK) return s;
+    rmark("prepared");
+    const bool p2pl = h->prm.cost == REG_COST_P2PL;
+    float T_start[16];
+    if (p2pl)
+        m4_identity(T_start);
+    else
+        std::memcpy(T_start, Ti, 64);
+    s = init_iter_state(h, T_start, 1);
+    if (s != REG_OK) return s;
+    rmark("iter state");
+    h->profiling = h->prm.profile_loop != 0;
+    // loop_ms: HIP events only when profiling (record + synchronise cost ~20 us of host time per registration);
+    // otherwise the host clock around the loop -- the loop ends when the last update kernel's mirror has arrived
+    const bool event_timing = h->profiling || getenv("O3D_EVENT_TIMING") != nullptr;
+    if (event_timing) HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    const auto t_loop_begin = std::chrono::steady_clock::now();
+    rmark("ev0");
+    const unsigned long long seq0 = h->seq;
+    const int fixed = h->prm.fixed_iters;
+    const int limit = fixed > 0 ? fixed : h->prm.max_iter;
+    // Iterations 0..kGenericFirst-1 run on the generic (select-based) path: the trimmed limit still moves too
+    // much to be predicted.  Afterwards the fused two-kernel iteration is used; if its band prediction fails the
+    // device stalls the queue and the host repairs that iteration on the generic path.
+    const bool can_fuse = p2pl && h->prm.disable_fused != 1;
+    const bool trimming = p2pl && h->prm.use_trimmed && h->prm.trim_ratio != 1.0f;
+    const int kGenericFirst = trimming ? 2 : 1;
+    const int kAhead = getenv("O3D_KAHEAD") ? atoi(getenv("O3D_KAHEAD")) : 2;
+    const HostMirror* mir = h->h_mirror;
+    int generic_left = kGenericFirst;
+    const bool trace = getenv("O3D_TRACE") != nullptr;
+    const float settle_tol = getenv("O3D_SETTLE") ? (float)atof(getenv("O3D_SETTLE")) : 0.05f;
+    unsigned long long last_traced = 0;
+    const auto t_loop0 = std::chrono::steady_clock::now();
+    unsigned long long acked = seq0;   // every sequence <= acked has either reported or been a no-op
+    int stalls = 0;
+    for (;;) {
+        const unsigned long long m_seq = std::max(mirror_seq(h), seq0);
+        const bool any = m_seq > seq0;
+        if (any && mir->done) break;
+        if (any && mir->stall && m_seq > acked) {
+            // band prediction failed at sequence m_seq: everything enqueued behind it is a no-op; drain, repair
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            acked = h->seq;
+            generic_left = 2;
+            ++stalls;
+            continue;
+        }
+        if (trace && m_seq != last_traced) {
+            last_traced = m_seq;
+            fprintf(stderr, "[o3dreg] seq %llu iter %d stall %d band_n %d limit %.6g prev %.6g band [%.6g, %.6g)\n",
+                    m_seq - seq0, mir->iterations, mir->stall, mir->stall ? mir->band_count : mir->pad_nband, mir->limit_last, mir->limit_prev,
+                    mir->band_lo, mir->band_hi);
+        }
+        acked = std::max(acked, m_seq);
+        const int completed = any ? mir->iterations : 0;
+        const int inflight = (int)(h->seq - acked);
+        if (completed + inflight < limit && inflight < kAhead) {
+            // fuse only once the trimmed limit has settled (last two seen limits within 5 %): the band is then
+            // narrow (few hundred records) and the prediction practically never fails
+            bool settled = true;
+            if (trimming) {
+                settled = any && mir->limit_prev < INFINITY && mir->limit_last < INFINITY &&
+                          std::fabs(mir->limit_last - mir->limit_prev) <= settle_tol * mir->limit_last;
+            }
+            const auto tq0 = std::chrono::steady_clock::now();
+            const bool go_generic = !can_fuse || generic_left > 0 || !settled;
+            if (go_generic) {
+                s = enqueue_iteration(h, true);   // weights are always written: reg_get_correspondences reports them
+                if (generic_left > 0) --generic_left;
+            } else {
+                // Fixed iteration count: nothing the host could learn changes what has to run, so the whole rest of
+                // the registration is submitted in one go (a failed band prediction turns what follows into no-ops
+                // and is repaired above).  Submitting while the device crosses a kernel boundary costs about 6 us per
+                // iteration (measured: rocprofv3 timeline, profiles/), hence no trickle-feeding here.
+                int burst = fixed > 0 && !getenv("O3D_NO_BURST") ? limit - (completed + inflight) : 1;
+                for (; burst > 0 && s == REG_OK; --burst) s = enqueue_fused(h, true);
+            }
+            if (trace) {
+                const auto tq1 = std::chrono::steady_clock::now();
+                fprintf(stderr, "[o3dreg] t=%.1fus enqueue seq %llu (%s) took %.1fus; mirror at %llu\n",
+                        std::chrono::duration<double, std::micro>(tq0 - t_loop0).count(), h->seq - seq0,
+                        go_generic ? "generic" : "fused", std::chrono::duration<double, std::micro>(tq1 - tq0).count(),
+                        std::max(mirror_seq(h), seq0) - seq0);
+            }
+            if (s != REG_OK) return s;
+            continue;
+        }
+        if (inflight == 0) break;  // nothing in flight and nothing left to enqueue
+        s = wait_seq(h, acked + 1);
+        if (s != REG_OK) return s;
+        if (mirror_seq(h) <= acked) {
+            // the stream drained without a report: the remaining sequences were no-ops (done or stalled earlier)
+            if (hipStreamQuery(h->stream) == hipSuccess && mirror_seq(h) <= acked) acked = h->seq;
+        }
+    }
+    h->last_stalls = stalls;
+    rmark("loop done");
+    if (event_timing) {
+        HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+        HIPCHK(h, hipEventSynchronize(h->ev1));
+        (void)hipEventElapsedTime(&res->loop_ms, h->ev0, h->ev1);
+    } else {
+        res->loop_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_loop_begin).count();
+    }
+    HIPCHK(h, hipGetLastError());
+    rmark("loop timed");
+    if (getenv("O3D_STAMPS")) {
+        fprintf(stderr, "update kernel stamps (cycles): reduce %llu [rows %llu select %llu band-add %llu] solve %llu update+check %llu mirror %llu\n", mir->stamps[0],
+                mir->stamps[4], mir->stamps[5], mir->stamps[6], mir->stamps[1], mir->stamps[2], mir->stamps[3]);
+        fprintf(stderr, "   select detail: verify+stage-issue %llu, zero+hist+barriers %llu, wave0 pick/rank %llu\n", mir->stamps[3], mir->stamps[7] >> 32, mir->stamps[7] & 0xffffffffull);
+    }
+    if (h->profiling) {
+        for (size_t i = 0; i + 1 < h->prof_ev.size(); i += 2) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, h->prof_ev[i], h->prof_ev[i + 1]) == hipSuccess) {
+                const int kind = h->prof_kind[i / 2];
+                res->prof_ms[kind] += ms;
+                res->prof_launches[kind] += 1;
+            }
+        }
+        for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
+        h->prof_ev.clear();
+        h->prof_kind.clear();
+        h->profiling = false;
+    }
+    res->iterations = mir->iterations;
+    for (int k = 0; k < 6; ++k) {
+        res->localizable[k] = h->prm.use_xicp ? mir->localizable[k] : 1;
+        res->xicp_combined[k] = mir->xicp_comb[k];
+        res->xicp_high[k] = mir->xicp_high[k];
+    }
+    res->n_constraints = h->prm.use_xicp ? mir->n_constraints : 0;
+    res->converged = mir->converged;
+    res->max_iter_reached = mir->max_iter_reached;
+    res->rank_last = mir->rank_last;
+    fill_result(h, mir->sums, res);
+    if (mir->status != REG_OK) {
+        h->err = mir->sums[29] == 0.0 ? "No matches available for computing distance quantiles"
+                                      : "ErrorMinimizer: no point to minimize";
+        return (reg_status)mir->status;
+    }
+    float T_iter[16], Tout_row[16];
+    std::memcpy(T_iter, mir->T, 64);
+    compose_rowmajor(h, T_iter, Tout_row, /*later_kernel_reported=*/true);
+    row_to_col(T_iter, res->T_iter_last);
+    row_to_col(Tout_row, T_out);
+    res->n_band_stalls = h->last_stalls;
+    rmark("return");
+    return REG_OK;
+}
+
+reg_status reg_compute(reg_handle* h, const float* xyz, int64_t xyz_stride, const float* nrm, int64_t nrm_stride,
+                       const float* cov, int64_t n, int on_device, const float T_init[16], float T_out[16],
+                       reg_result* res) {
+    reg_status s = reg_set_source(h, xyz, xyz_stride, nrm, nrm_stride, cov, n, on_device);
+    if (s != REG_OK) return s;
+    return reg_register(h, T_init, T_out, res);
+}
+
+reg_status reg_get_correspondences(reg_handle* h, int32_t* ids, float* d2, float* w) {
+    reg_status s = check_ready(h, true);
+    if (s != REG_OK) return s;
+    if (!h->have_match) {
+        h->err = "no iteration has run yet";
+        return REG_NOT_CONFIGURED;
+    }
+    HIPCHK(h, hipSetDevice(h->prm.device));
+    const int64_t n = h->n;
+    if (ids) {
+        HIPCHK(h, h->i_ids.reserve((size_t)n * 4));
+        k_ids_from_pos<<<grid_for(n), 256, 0, h->stream>>>(h->i_pos.as<int>(), h->t_pts.as<float4>(), n, h->perm,
+                                                           h->i_ids.as<int32_t>());
+        HIPCHK(h, hipMemcpyAsync(ids, h->i_ids.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(h, h->i_tmpf.reserve((size_t)n * 8));
+    if (d2) {
+        k_unpermute_f32<<<grid_for(n), 256, 0, h->stream>>>(h->i_d2.as<float>(), n, h->perm, h->i_tmpf.as<float>());
+        HIPCHK(h, hipMemcpyAsync(d2, h->i_tmpf.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    }
+    if (w) {
+        k_unpermute_f32<<<grid_for(n), 256, 0, h->stream>>>(h->i_w.as<float>(), n, h->perm, h->i_tmpf.as<float>() + n);
+        HIPCHK(h, hipMemcpyAsync(w, h->i_tmpf.as<float>() + n, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return REG_OK;
+}
+
+}  // extern "C"
