@@ -302,6 +302,18 @@ REG_API reg_status reg_voxelize_within_volume(reg_handle* h, const double* xyz, 
                                               double* out_xyz, double* out_normals, double* out_covs, int64_t* n_out,
                                               int64_t* n_outside);
 
+/* Space carving (open3d_slam/src/Submap.cpp:130-143 -> helpers.cpp:238-283, getIdxsOfCarvedPoints): every scan point
+   (already in the map frame) casts a ray from the sensor; the ray is sampled every `voxel_size` up to
+   max(voxel_size, min(|p - sensor| - truncation, max_ray)); map points that share a voxel (floor(p * (1/voxel_size)),
+   VoxelHashMap.hpp:43-51) with a sample are removed when |direction . normalized(normal)| > min_dot (always, without
+   normals).  Only map points inside `subset` (the map builder's cropper, may be NULL = all) take part.  All in double,
+   one rounding per operation.  removed[]: ascending map indices (the reference returns them in std::unordered_set
+   order), capacity m.  Rays of zero length are skipped (the reference divides by zero there). */
+REG_API reg_status reg_carve_indices(reg_handle* h, const double* map_xyz, const double* map_normals, int64_t m,
+                                     const double* scan_xyz, int64_t n_scan, int on_device, const double sensor[3],
+                                     const reg_crop* subset, double voxel_size, double max_ray, double truncation,
+                                     double min_dot, int32_t* removed, int64_t* n_removed);
+
 /* Introspection of the search structure (tests, DESIGN.md numbers). */
 typedef struct {
     int64_t n_points;

@@ -74,7 +74,7 @@ EXPORTS = ["reg_default_params", "reg_shipped_params", "reg_create", "reg_destro
            "reg_solve_update", "reg_host_solve6", "reg_host_x_to_T", "reg_host_centroid", "reg_get_target_info", "reg_profile_kernels", "reg_source_centroid_sums", "reg_prepare_centroid", "reg_compose",
            "reg_dist_begin", "reg_dist_buffers", "reg_dist_phase", "reg_dist_finish",
            "reg_dist_fused_buffers", "reg_dist_poll", "reg_estimate_normals", "reg_host_solve6_xicp",
-           "reg_set_target_f64", "reg_get_target_source_indices", "reg_voxelize_within_volume"]
+           "reg_set_target_f64", "reg_get_target_source_indices", "reg_voxelize_within_volume", "reg_carve_indices"]
 
 
 def lib_path() -> str:
@@ -130,6 +130,8 @@ def load_library():
     lib.reg_host_solve6_xicp.restype = C.c_int
     lib.reg_set_target_f64.argtypes = [vp, vp, vp, vp, i64, C.c_int, C.POINTER(RegCrop), C.POINTER(C.c_int64)]
     lib.reg_get_target_source_indices.argtypes = [vp, vp]
+    lib.reg_carve_indices.argtypes = [vp, vp, vp, i64, vp, i64, C.c_int, C.POINTER(C.c_double), C.POINTER(RegCrop),
+                                      C.c_double, C.c_double, C.c_double, C.c_double, vp, C.POINTER(C.c_int64)]
     lib.reg_voxelize_within_volume.argtypes = [vp, vp, vp, vp, i64, C.c_int, C.POINTER(RegCrop), C.c_double, vp, vp, vp,
                                                C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.reg_host_centroid.argtypes = [f32p, i64, i64, f32p]
@@ -305,6 +307,21 @@ class Registration:
                                                          _ptr(on), _ptr(oc), C.byref(n_out), C.byref(n_outside)))
         k = int(n_out.value)
         return ox[:k], (on[:k] if on is not None else None), (oc[:k] if oc is not None else None), int(n_outside.value)
+
+    def carve_indices(self, map_xyz, scan_xyz, sensor, voxel_size=0.1, max_ray=20.0, truncation=0.1, min_dot=0.5,
+                      map_normals=None, subset=None):
+        """Space carving (helpers.cpp:238-283): ascending indices of the map points to remove."""
+        mp = np.ascontiguousarray(map_xyz, np.float64)
+        sp = np.ascontiguousarray(scan_xyz, np.float64)
+        nr = np.ascontiguousarray(map_normals, np.float64) if map_normals is not None else None
+        out = np.empty(max(mp.shape[0], 1), np.int32)
+        sen = (C.c_double * 3)(*[float(v) for v in sensor])
+        c = self._crop_struct(subset)
+        n = C.c_int64(0)
+        self._check(self._lib.reg_carve_indices(self._h, _ptr(mp), _ptr(nr), mp.shape[0], _ptr(sp), sp.shape[0], 0, sen,
+                                                C.byref(c) if c is not None else None, float(voxel_size), float(max_ray),
+                                                float(truncation), float(min_dot), _ptr(out), C.byref(n)))
+        return out[:int(n.value)].copy()
 
     def target_source_indices(self):
         idx = np.empty(self.n_target_kept, np.int32)

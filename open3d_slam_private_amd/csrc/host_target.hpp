@@ -43,6 +43,7 @@ struct reg_handle {
     DevBuf c_in_xyz, c_in_nrm, c_in_cov, c_flags, c_offs, c_xyz, c_nrm, c_cov, c_idx;   // reg_set_target_f64
     int64_t crop_kept = 0;
     DevBuf v_fout, v_oout, v_oxyz, v_onrm, v_ocov;   // reg_voxelize_within_volume
+    DevBuf v_ukeys, v_ustart;                        // reg_carve_indices
     bool xicp_pending = false;     // the next generic iteration is followed by the analysis kernels
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_iter = nullptr;
     bool iter_copy_pending = false;
@@ -198,7 +199,7 @@ void reg_destroy(reg_handle* h) {
     if (h->normals_ws) reg_destroy(h->normals_ws);
     h->n_out.release();
     h->i_xicp.release();
-    for (DevBuf* b : {&h->c_in_xyz, &h->c_in_nrm, &h->c_in_cov, &h->c_flags, &h->c_offs, &h->c_xyz, &h->c_nrm, &h->c_cov, &h->c_idx, &h->v_fout, &h->v_oout, &h->v_oxyz, &h->v_onrm, &h->v_ocov}) b->release();
+    for (DevBuf* b : {&h->c_in_xyz, &h->c_in_nrm, &h->c_in_cov, &h->c_flags, &h->c_offs, &h->c_xyz, &h->c_nrm, &h->c_cov, &h->c_idx, &h->v_fout, &h->v_oout, &h->v_oxyz, &h->v_onrm, &h->v_ocov, &h->v_ukeys, &h->v_ustart}) b->release();
     h->n_eig.release();
     h->n_cov.release();
     h->n_ids.release();
@@ -800,6 +801,143 @@ reg_status reg_voxelize_within_volume(reg_handle* h, const double* xyz, const do
     HIPCHK(h, hipGetLastError());
     if (n_out) *n_out = total;
     if (n_outside) *n_outside = n_outs;
+    return REG_OK;
+}
+
+reg_status reg_carve_indices(reg_handle* h, const double* map_xyz, const double* map_normals, int64_t m,
+                             const double* scan_xyz, int64_t n_scan, int on_device, const double sensor[3],
+                             const reg_crop* subset, double voxel_size, double max_ray, double truncation, double min_dot,
+                             int32_t* removed, int64_t* n_removed) {
+    if (!h) return REG_BAD_ARGUMENT;
+    if (!h->device_ok) return REG_DEVICE_ERROR;
+    if (n_removed) *n_removed = 0;
+    if (m < 0 || n_scan < 0 || m > 0x7fffffffLL || n_scan > 0x7fffffffLL || !sensor || !(voxel_size > 0.0) ||
+        (m > 0 && (!map_xyz || !removed)) || (n_scan > 0 && !scan_xyz)) {
+        if (h) h->err = "reg_carve_indices: bad argument (voxel_size > 0, sensor, arrays)";
+        return REG_BAD_ARGUMENT;
+    }
+    if (m == 0 || n_scan == 0) return REG_OK;
+    CropCfg c;
+    std::memset(&c, 0, sizeof(c));
+    if (subset) {
+        if (subset->type < REG_CROP_NONE || subset->type > REG_CROP_CYLINDER) return REG_BAD_ARGUMENT;
+        c.type = subset->type;
+        c.cx = subset->center[0];
+        c.cy = subset->center[1];
+        c.cz = subset->center[2];
+        c.rmin = subset->radius_min;
+        c.rmax = subset->radius_max;
+        c.zmin = subset->min_z;
+        c.zmax = subset->max_z;
+    }
+    HIPCHK(h, hipSetDevice(h->prm.device));
+    const double *d_map = map_xyz, *d_nrm = map_normals, *d_scan = scan_xyz;
+    if (!on_device) {
+        HIPCHK(h, h->c_in_xyz.reserve((size_t)m * 24));
+        HIPCHK(h, hipMemcpyAsync(h->c_in_xyz.p, map_xyz, (size_t)m * 24, hipMemcpyHostToDevice, h->stream));
+        d_map = h->c_in_xyz.as<double>();
+        if (map_normals) {
+            HIPCHK(h, h->c_in_nrm.reserve((size_t)m * 24));
+            HIPCHK(h, hipMemcpyAsync(h->c_in_nrm.p, map_normals, (size_t)m * 24, hipMemcpyHostToDevice, h->stream));
+            d_nrm = h->c_in_nrm.as<double>();
+        }
+        HIPCHK(h, h->c_in_cov.reserve((size_t)n_scan * 24));
+        HIPCHK(h, hipMemcpyAsync(h->c_in_cov.p, scan_xyz, (size_t)n_scan * 24, hipMemcpyHostToDevice, h->stream));
+        d_scan = h->c_in_cov.as<double>();
+    }
+    const double inv = 1.0 / voxel_size;
+    // 1. candidate map points (inside the subset volume), keyed by voxel, stably sorted
+    HIPCHK(h, h->c_flags.reserve((size_t)m * 4));
+    HIPCHK(h, h->c_offs.reserve((size_t)m * 4));
+    HIPCHK(h, h->v_fout.reserve((size_t)m * 4));
+    HIPCHK(h, h->v_oout.reserve((size_t)m * 4));
+    HIPCHK(h, h->t_misc.reserve(256));
+    HIPCHK(h, hipMemsetAsync(h->t_misc.p, 0, 4, h->stream));
+    k_vox_classify<<<grid_for(m), 256, 0, h->stream>>>(d_map, m, c, inv, h->c_flags.as<uint32_t>(), h->v_fout.as<uint32_t>(),
+                                                       h->t_misc.as<uint32_t>());
+    size_t tb = 0;
+    HIPCHK(h, rocprim::exclusive_scan(nullptr, tb, h->c_flags.as<uint32_t>(), h->c_offs.as<uint32_t>(), 0u, (size_t)m,
+                                      rocprim::plus<uint32_t>(), h->stream));
+    HIPCHK(h, h->t_tmp.reserve(tb));
+    HIPCHK(h, rocprim::exclusive_scan(h->t_tmp.p, tb, h->c_flags.as<uint32_t>(), h->c_offs.as<uint32_t>(), 0u, (size_t)m,
+                                      rocprim::plus<uint32_t>(), h->stream));
+    uint32_t tail[3] = {0, 0, 0};
+    HIPCHK(h, hipMemcpyAsync(&tail[0], h->c_offs.as<uint32_t>() + (m - 1), 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(&tail[1], h->c_flags.as<uint32_t>() + (m - 1), 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(&tail[2], h->t_misc.p, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (tail[2]) {
+        h->err = "voxel_size too small for the extent of the map (voxel index exceeds 2^20)";
+        return REG_BAD_ARGUMENT;
+    }
+    const int64_t n_in = (int64_t)tail[0] + tail[1];
+    if (n_in == 0) return REG_OK;
+    HIPCHK(h, h->t_keys.reserve((size_t)n_in * 8));
+    HIPCHK(h, h->t_keys2.reserve((size_t)n_in * 8));
+    HIPCHK(h, h->t_vals.reserve((size_t)n_in * 4));
+    HIPCHK(h, h->t_vals2.reserve((size_t)n_in * 4));
+    k_carve_keys<<<grid_for(m), 256, 0, h->stream>>>(d_map, m, inv, h->c_flags.as<uint32_t>(), h->c_offs.as<uint32_t>(),
+                                                     h->t_keys.as<uint64_t>(), h->t_vals.as<uint32_t>());
+    size_t sb = 0;
+    HIPCHK(h, rocprim::radix_sort_pairs(nullptr, sb, h->t_keys.as<uint64_t>(), h->t_keys2.as<uint64_t>(),
+                                        h->t_vals.as<uint32_t>(), h->t_vals2.as<uint32_t>(), (size_t)n_in, 0, 3 * kVoxBits,
+                                        h->stream));
+    HIPCHK(h, h->t_tmp.reserve(sb));
+    HIPCHK(h, rocprim::radix_sort_pairs(h->t_tmp.p, sb, h->t_keys.as<uint64_t>(), h->t_keys2.as<uint64_t>(),
+                                        h->t_vals.as<uint32_t>(), h->t_vals2.as<uint32_t>(), (size_t)n_in, 0, 3 * kVoxBits,
+                                        h->stream));
+    // 2. unique voxels
+    HIPCHK(h, h->t_flags.reserve((size_t)n_in * 4));
+    HIPCHK(h, h->t_scan.reserve((size_t)n_in * 4));
+    k_vox_heads<<<grid_for(n_in), 256, 0, h->stream>>>(h->t_keys2.as<uint64_t>(), n_in, h->t_flags.as<uint32_t>());
+    size_t eb = 0;
+    HIPCHK(h, rocprim::exclusive_scan(nullptr, eb, h->t_flags.as<uint32_t>(), h->t_scan.as<uint32_t>(), 0u, (size_t)n_in,
+                                      rocprim::plus<uint32_t>(), h->stream));
+    HIPCHK(h, h->t_tmp.reserve(eb));
+    HIPCHK(h, rocprim::exclusive_scan(h->t_tmp.p, eb, h->t_flags.as<uint32_t>(), h->t_scan.as<uint32_t>(), 0u, (size_t)n_in,
+                                      rocprim::plus<uint32_t>(), h->stream));
+    uint32_t lv[2] = {0, 0};
+    HIPCHK(h, hipMemcpyAsync(&lv[0], h->t_scan.as<uint32_t>() + (n_in - 1), 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(&lv[1], h->t_flags.as<uint32_t>() + (n_in - 1), 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const int64_t nu = (int64_t)lv[0] + lv[1];
+    HIPCHK(h, h->v_ukeys.reserve((size_t)nu * 8));
+    HIPCHK(h, h->v_ustart.reserve((size_t)(nu + 1) * 4));
+    k_carve_unique<<<grid_for(n_in), 256, 0, h->stream>>>(h->t_keys2.as<uint64_t>(), n_in, h->t_flags.as<uint32_t>(),
+                                                          h->t_scan.as<uint32_t>(), h->v_ukeys.as<uint64_t>(),
+                                                          h->v_ustart.as<uint32_t>());
+    const uint32_t n_in32 = (uint32_t)n_in;
+    HIPCHK(h, hipMemcpyAsync(h->v_ustart.as<uint32_t>() + nu, &n_in32, 4, hipMemcpyHostToDevice, h->stream));
+    // 3. rays -> marks (v_fout / v_oout are reused as mark / offsets over the map)
+    HIPCHK(h, hipMemsetAsync(h->v_fout.p, 0, (size_t)m * 4, h->stream));
+    k_carve_rays<<<grid_for(n_scan), 256, 0, h->stream>>>(d_scan, n_scan, sensor[0], sensor[1], sensor[2], voxel_size, max_ray,
+                                                          truncation, min_dot, inv, h->v_ukeys.as<uint64_t>(),
+                                                          h->v_ustart.as<uint32_t>(), nu, h->t_vals2.as<uint32_t>(), d_nrm,
+                                                          h->v_fout.as<uint32_t>());
+    // 4. ascending list of marked map indices
+    HIPCHK(h, rocprim::exclusive_scan(nullptr, tb, h->v_fout.as<uint32_t>(), h->v_oout.as<uint32_t>(), 0u, (size_t)m,
+                                      rocprim::plus<uint32_t>(), h->stream));
+    HIPCHK(h, h->t_tmp.reserve(tb));
+    HIPCHK(h, rocprim::exclusive_scan(h->t_tmp.p, tb, h->v_fout.as<uint32_t>(), h->v_oout.as<uint32_t>(), 0u, (size_t)m,
+                                      rocprim::plus<uint32_t>(), h->stream));
+    uint32_t rt[2] = {0, 0};
+    HIPCHK(h, hipMemcpyAsync(&rt[0], h->v_oout.as<uint32_t>() + (m - 1), 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(&rt[1], h->v_fout.as<uint32_t>() + (m - 1), 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const int64_t nr = (int64_t)rt[0] + rt[1];
+    int32_t* d_out = removed;
+    if (!on_device) {
+        HIPCHK(h, h->c_idx.reserve((size_t)std::max<int64_t>(nr, 1) * 4));
+        d_out = h->c_idx.as<int32_t>();
+        h->crop_kept = 0;   // c_idx no longer holds the crop map of reg_set_target_f64
+    }
+    if (nr > 0) {
+        k_carve_collect<<<grid_for(m), 256, 0, h->stream>>>(h->v_fout.as<uint32_t>(), h->v_oout.as<uint32_t>(), m, d_out);
+        if (!on_device) HIPCHK(h, hipMemcpyAsync(removed, d_out, (size_t)nr * 4, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    if (n_removed) *n_removed = nr;
     return REG_OK;
 }
 

@@ -150,3 +150,97 @@ __global__ void k_vox_reduce(const uint64_t* __restrict__ keys, const uint32_t* 
     if (cov)
         for (int k = 0; k < 9; ++k) ocov[9 * o + k] = cc[k] / dc;
 }
+
+// ---- space carving (helpers.cpp:238-283) ----
+// keys of the map points inside the subset volume (compacted by o_in), value = map index
+__global__ void k_carve_keys(const double* __restrict__ xyz, int64_t m, double inv, const uint32_t* __restrict__ f_in,
+                             const uint32_t* __restrict__ o_in, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= m || !f_in[i]) return;
+    const long long vx = (long long)floor(xyz[3 * i] * inv) + kVoxOff;
+    const long long vy = (long long)floor(xyz[3 * i + 1] * inv) + kVoxOff;
+    const long long vz = (long long)floor(xyz[3 * i + 2] * inv) + kVoxOff;
+    keys[o_in[i]] = ((uint64_t)vz << (2 * kVoxBits)) | ((uint64_t)vy << kVoxBits) | (uint64_t)vx;
+    vals[o_in[i]] = (uint32_t)i;
+}
+// unique voxel keys and the first sorted position of each (ustart[nu] = n is written by the host)
+__global__ void k_carve_unique(const uint64_t* __restrict__ keys, int64_t n, const uint32_t* __restrict__ heads,
+                               const uint32_t* __restrict__ uid, uint64_t* __restrict__ ukeys, uint32_t* __restrict__ ustart) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n || !heads[i]) return;
+    ukeys[uid[i]] = keys[i];
+    ustart[uid[i]] = (uint32_t)i;
+}
+__global__ void k_carve_rays(const double* __restrict__ scan, int64_t n_scan, double sx, double sy, double sz, double step,
+                             double max_ray, double trunc, double min_dot, double inv, const uint64_t* __restrict__ ukeys,
+                             const uint32_t* __restrict__ ustart, int64_t nu, const uint32_t* __restrict__ vals,
+                             const double* __restrict__ nrm, uint32_t* __restrict__ mark) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n_scan) return;
+    const double dx = scan[3 * i] - sx, dy = scan[3 * i + 1] - sy, dz = scan[3 * i + 2] - sz;
+    double a = dx * dx;
+    double b = dy * dy;
+    double s2 = a + b;
+    a = dz * dz;
+    s2 = s2 + a;
+    const double length = sqrt(s2);
+    if (!(length > 0.0) || !(length < INFINITY)) return;
+    const double ux = dx / length, uy = dy / length, uz = dz / length;
+    const double reach = fmax(step, fmin(length - trunc, max_ray));
+    double distance = 0.0;
+    while (distance < reach) {
+        double t = distance * ux;
+        const double px = t + sx;
+        t = distance * uy;
+        const double py = t + sy;
+        t = distance * uz;
+        const double pz = t + sz;
+        const double fx = floor(px * inv), fy = floor(py * inv), fz = floor(pz * inv);
+        if (fabs(fx) < (double)kVoxOff && fabs(fy) < (double)kVoxOff && fabs(fz) < (double)kVoxOff) {
+            const uint64_t key = ((uint64_t)((long long)fz + kVoxOff) << (2 * kVoxBits)) |
+                                 ((uint64_t)((long long)fy + kVoxOff) << kVoxBits) | (uint64_t)((long long)fx + kVoxOff);
+            int64_t lo = 0, hi = nu;   // first ukeys[lo] >= key
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (ukeys[mid] < key)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            if (lo < nu && ukeys[lo] == key) {
+                for (uint32_t j = ustart[lo]; j < ustart[lo + 1]; ++j) {
+                    const uint32_t id = vals[j];
+                    bool rm = true;
+                    if (nrm) {
+                        double n0 = nrm[3 * (size_t)id], n1 = nrm[3 * (size_t)id + 1], n2 = nrm[3 * (size_t)id + 2];
+                        double u = n0 * n0;
+                        double v = n1 * n1;
+                        double z2 = u + v;
+                        u = n2 * n2;
+                        z2 = z2 + u;
+                        if (z2 > 0.0) {
+                            const double r = sqrt(z2);
+                            n0 = n0 / r;
+                            n1 = n1 / r;
+                            n2 = n2 / r;
+                        }
+                        u = ux * n0;
+                        v = uy * n1;
+                        double d = u + v;
+                        u = uz * n2;
+                        d = d + u;
+                        rm = fabs(d) > min_dot;
+                    }
+                    if (rm) mark[id] = 1u;   // idempotent: no atomic needed
+                }
+            }
+        }
+        distance += step;
+    }
+}
+__global__ void k_carve_collect(const uint32_t* __restrict__ mark, const uint32_t* __restrict__ offs, int64_t m,
+                                int32_t* __restrict__ out) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= m || !mark[i]) return;
+    out[offs[i]] = (int32_t)i;
+}

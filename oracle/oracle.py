@@ -336,3 +336,43 @@ def voxelize_within_volume(xyz, voxel_size, inside_mask, normals=None, covs=None
     if cv is not None:
         oc = np.concatenate([cv[out_idx], np.array([acc[k][2] / float(acc[k][3]) for k in keys]).reshape(-1, 9)])
     return ox, on, oc, out_idx.size
+
+
+def carve_indices(map_xyz, scan_xyz, sensor, voxel_size=0.1, max_ray=20.0, truncation=0.1, min_dot=0.5, map_normals=None,
+                  subset_mask=None):
+    """getIdxsOfCarvedPoints (open3d_slam/src/helpers.cpp:238-283) restated with a dict of voxels; float64, operation by
+    operation.  Returns the ascending indices of the map points a scan ray passes through."""
+    mp = np.asarray(map_xyz, np.float64)
+    sp = np.asarray(scan_xyz, np.float64)
+    s = np.asarray(sensor, np.float64)
+    nr = np.asarray(map_normals, np.float64) if map_normals is not None else None
+    inv = 1.0 / float(voxel_size)
+    vox = {}
+    idxs = np.arange(mp.shape[0]) if subset_mask is None else np.nonzero(subset_mask)[0]
+    for i in idxs:
+        key = (int(np.floor(mp[i, 0] * inv)), int(np.floor(mp[i, 1] * inv)), int(np.floor(mp[i, 2] * inv)))
+        vox.setdefault(key, []).append(int(i))
+    remove = set()
+    for p in sp:
+        d = p - s
+        length = np.sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2])
+        if not (length > 0.0) or not np.isfinite(length):
+            continue
+        u = d / length
+        reach = max(voxel_size, min(length - truncation, max_ray))
+        dist = 0.0
+        while dist < reach:
+            cur = dist * u + s
+            key = (int(np.floor(cur[0] * inv)), int(np.floor(cur[1] * inv)), int(np.floor(cur[2] * inv)))
+            for j in vox.get(key, ()):
+                ok = True
+                if nr is not None:
+                    n = nr[j]
+                    z2 = (n[0] * n[0] + n[1] * n[1]) + n[2] * n[2]
+                    if z2 > 0:
+                        n = n / np.sqrt(z2)
+                    ok = abs((u[0] * n[0] + u[1] * n[1]) + u[2] * n[2]) > min_dot
+                if ok:
+                    remove.add(j)
+            dist += voxel_size
+    return np.array(sorted(remove), np.int32)

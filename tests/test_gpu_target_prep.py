@@ -123,3 +123,36 @@ def test_voxelize_within_volume_is_bit_exact(with_attrs):
     assert np.array_equal(vx[1], (neg[0] + neg[1]) / 2.0) and np.array_equal(vx[2], neg[2])
     with pytest.raises(capi.RegError):                                  # voxel index overflow fails loudly
         reg.voxelize_within_volume(np.array([[1e9, 0.0, 0.0]]), 1e-3, None)
+
+
+@pytest.mark.parametrize("with_normals", [True, False])
+def test_space_carving_removes_exactly_the_points_the_restatement_removes(with_normals):
+    """getIdxsOfCarvedPoints (helpers.cpp:238-283): index work -> the removed set must be identical."""
+    rng = np.random.default_rng(21)
+    sc = synth.make_scene(1500, 40000, seed=22)
+    mp = sc.tgt_xyz.astype(np.float64)
+    # "dynamic object": a blob of map points floating in free space between the sensor and the walls
+    blob = np.array([3.0, 1.0, 1.2]) + rng.normal(scale=0.15, size=(400, 3))
+    mp = np.concatenate([mp, blob])
+    nrm = None
+    if with_normals:
+        bn = rng.normal(size=(400, 3))
+        nrm = np.concatenate([sc.tgt_nrm.astype(np.float64), bn])     # un-normalised on purpose (normalized() inside)
+    scan = sc.src_xyz.astype(np.float64)[:1500]                        # already "in the map frame" for this test
+    sensor = (0.2, -0.1, 0.4)
+    subset = dict(type=capi.CROP_MAX_RADIUS, center=sensor, radius_max=18.0)
+    reg = capi.Registration(capi.default_params())
+    got = reg.carve_indices(mp, scan, sensor, voxel_size=0.1, max_ray=20.0, truncation=0.1, min_dot=0.5,
+                            map_normals=nrm, subset=subset)
+    mask = orc.crop_mask(mp, 1, center=sensor, radius_max=18.0)
+    want = orc.carve_indices(mp, scan, sensor, 0.1, 20.0, 0.1, 0.5, nrm, mask)
+    assert want.size > 50
+    assert np.array_equal(got, want)
+    assert np.all(np.diff(got) > 0)
+    if not with_normals:
+        assert (got >= sc.tgt_xyz.shape[0]).sum() > 20                  # rays pass through the floating blob
+    # degenerate inputs
+    assert reg.carve_indices(mp, np.array([sensor]), sensor).size == 0      # zero-length ray: skipped
+    assert reg.carve_indices(mp[:0], scan, sensor).size == 0
+    with pytest.raises(capi.RegError):
+        reg.carve_indices(mp, scan, sensor, voxel_size=0.0)
