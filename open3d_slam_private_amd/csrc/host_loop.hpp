@@ -442,7 +442,7 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
     const HostMirror* mir = h->h_mirror;
     int generic_left = kGenericFirst;
     const bool trace = getenv("O3D_TRACE") != nullptr;
-    const float settle_tol = getenv("O3D_SETTLE") ? (float)atof(getenv("O3D_SETTLE")) : 0.05f;
+    const float settle_tol = getenv("O3D_SETTLE") ? (float)atof(getenv("O3D_SETTLE")) : 0.25f;
     unsigned long long last_traced = 0;
     const auto t_loop0 = std::chrono::steady_clock::now();
     unsigned long long acked = seq0;   // every sequence <= acked has either reported or been a no-op
@@ -469,8 +469,10 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
         const int completed = any ? mir->iterations : 0;
         const int inflight = (int)(h->seq - acked);
         if (completed + inflight < limit && inflight < kAhead) {
-            // fuse only once the trimmed limit has settled (last two seen limits within 5 %): the band is then
-            // narrow (few hundred records) and the prediction practically never fails
+            // fuse once the trimmed limit is settling (last two limits the host has seen within 25 %): by the time the
+            // first fused iteration runs, the lookahead has put two more iterations in between, and its band comes from
+            // the device's latest pair of limits anyway -- narrow (few hundred records), practically never mispredicted
+            // (measured on three scenes: 5 % / 25 % / 50 % / none: no stalls, 25 % fastest by 1-3 %)
             bool settled = true;
             if (trimming) {
                 settled = any && mir->limit_prev < INFINITY && mir->limit_last < INFINITY &&

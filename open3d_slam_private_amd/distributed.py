@@ -149,7 +149,7 @@ class FusedStreamDistributedRegistration(StreamDistributedRegistration):
     update kernel writes (reg_dist_poll) and stays at most `ahead` iterations ahead of it."""
 
     def __init__(self, reg, use_trimmed, trim_ratio, iters, world, rank, dist=None, device=None, all_reduce=None,
-                 all_gather=None, ahead=3, fixed=True, settle_tol=0.05):
+                 all_gather=None, ahead=3, fixed=True, settle_tol=0.25):
         super().__init__(reg, use_trimmed, iters, dist=dist, device=device, all_reduce=all_reduce)
         import torch
         self.world, self.rank, self.ahead, self.fixed, self.settle_tol = world, rank, ahead, fixed, settle_tol
