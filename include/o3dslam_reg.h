@@ -225,6 +225,9 @@ typedef struct {
 REG_API reg_status reg_dist_fused_buffers(reg_handle* h, int n_ranks, int rank, void** contrib, void** gathered,
                                           int64_t* contrib_bytes);
 REG_API reg_status reg_dist_poll(reg_handle* h, reg_dist_status* out);
+/* use_xicp on the distributed path: on the FIRST iteration, after phase 4, run phase 7, all-reduce (sum) the 4 doubles at
+   *center, phase 8, all-reduce the 12 doubles at *sums, phase 9 (reports with the sequence number of phase 4). */
+REG_API reg_status reg_dist_xicp_buffers(reg_handle* h, void** center, void** sums);
 
 /* Host-side pieces of the path, exported so they can be checked without a GPU
    (PointToPlane.cpp:112-265 solve, :327-381 x -> 4x4; column-major 4x4). */

@@ -132,11 +132,6 @@ reg_status reg_solve_update(const reg_params* p, const double sums[32], const fl
 reg_status reg_dist_begin(reg_handle* h, const float T_start[16]) {
     reg_status s = check_ready(h, true);
     if (s != REG_OK) return s;
-    if (h->prm.use_xicp) {
-        h->err = "use_xicp: the localizability analysis is not available on the distributed path (its information sums "
-                 "are not exchanged between ranks yet)";
-        return REG_BAD_ARGUMENT;
-    }
     float Tr[16];
     if (T_start) {
         col_to_row(T_start, Tr);
@@ -147,6 +142,7 @@ reg_status reg_dist_begin(reg_handle* h, const float T_start[16]) {
     }
     HIPCHK(h, hipSetDevice(h->prm.device));
     s = init_iter_state(h, Tr, 1);
+    h->xicp_pending = false;   // the distributed path drives the analysis through phases 7-9
     if (s != REG_OK) return s;
     HIPCHK(h, hipMemsetAsync(h->i_hist.p, 0, 3 * 2048 * 4, h->stream));
     h->dist_seq0 = h->seq;
@@ -228,7 +224,7 @@ reg_status reg_dist_phase(reg_handle* h, int phase) {
                 k_linearize_p2pl<<<h->n_blocks, 256, 0, h->stream>>>(
                     h->s_xyz.as<float4>(), h->has_snrm ? h->s_nrm.as<float4>() : nullptr, h->n, it, h->i_pos.as<int>(),
                     h->i_d2.as<float>(), h->t_pts.as<float4>(), h->t_nrm.as<float4>(), f, st, hist0 + 4096, hist0 + 2048,
-                    h->shift0, nullptr, h->i_partials.as<double>());
+                    h->shift0, h->prm.use_xicp ? h->i_w.as<float>() : nullptr, h->i_partials.as<double>());
             } else {
                 k_linearize_gicp<<<h->n_blocks, 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->s_cov.as<float4>(), h->n, it,
                                                                      h->i_pos.as<int>(), h->i_d2.as<float>(),
@@ -242,7 +238,8 @@ reg_status reg_dist_phase(reg_handle* h, int phase) {
             ++h->seq;
             k_reduce_update<<<1, 1024, 0, h->stream>>>(h->i_sums.as<double>(), 1, h->i_iter.as<IterState>(), h->d_mirror,
                                                        h->seq, 0, nullptr, nullptr,
-                                                       h->prm.cost == REG_COST_P2PL ? st : nullptr, nullptr, 0, 0, nullptr);
+                                                       h->prm.cost == REG_COST_P2PL ? st : nullptr, nullptr, 0, 0,
+                                                       h->prm.use_xicp ? h->i_xicp.as<XicpState>() : nullptr);
             break;
         case 5: {
             // fused iteration, local half: search + weights + normal equations + band records (into this rank's
@@ -268,9 +265,46 @@ reg_status reg_dist_phase(reg_handle* h, int phase) {
                                                        nullptr, h->i_w.as<float>(), nullptr, h->d_gathered.as<float>(),
                                                        h->dist_ranks, h->dist_rank, nullptr);
             break;
+        // R8x on the distributed path, first iteration only: after phase 4 (which then only stashes the eigen-directions)
+        //   7: this rank's share of the matched-point centre   -> caller all-reduces the 4 doubles of reg_dist_xicp_buffers
+        //   8: this rank's share of the 12 information sums    -> caller all-reduces them
+        //   9: decide, solve (constrained or not), update, report -- with the sequence number of phase 4
+        case 7:
+        case 8: {
+            if (!h->prm.use_xicp) return REG_BAD_ARGUMENT;
+            const int blocks = (int)std::min<int64_t>(512, (h->n + 255) / 256);
+            if (phase == 7)
+                k_xicp_center<<<blocks, 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->n, it, h->i_pos.as<int>(),
+                                                             h->i_w.as<float>(), h->i_xicp.as<XicpState>());
+            else
+                k_xicp_detect<<<blocks, 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->n, it, h->i_pos.as<int>(),
+                                                             h->i_w.as<float>(), h->t_nrm.as<float4>(),
+                                                             h->i_xicp.as<XicpState>());
+            break;
+        }
+        case 9:
+            if (!h->prm.use_xicp) return REG_BAD_ARGUMENT;
+            k_reduce_update<<<1, 1024, 0, h->stream>>>(nullptr, 0, h->i_iter.as<IterState>(), h->d_mirror, h->seq, 2, nullptr,
+                                                       nullptr, nullptr, nullptr, 0, 0, h->i_xicp.as<XicpState>());
+            break;
         default:
             return REG_BAD_ARGUMENT;
     }
+    return REG_OK;
+}
+
+reg_status reg_dist_xicp_buffers(reg_handle* h, void** center, void** sums) {
+    if (!h || !center || !sums) return REG_BAD_ARGUMENT;
+    if (!h->device_ok) return REG_DEVICE_ERROR;
+    if (!h->prm.use_xicp) {
+        h->err = "reg_dist_xicp_buffers: use_xicp is off";
+        return REG_NOT_CONFIGURED;
+    }
+    HIPCHK(h, hipSetDevice(h->prm.device));
+    HIPCHK(h, h->i_xicp.reserve(sizeof(XicpState)));
+    XicpState* xs = h->i_xicp.as<XicpState>();
+    *center = xs->center;   // 4 doubles
+    *sums = xs->comb;       // 12 doubles (comb[6] directly followed by high[6])
     return REG_OK;
 }
 
@@ -293,6 +327,12 @@ reg_status reg_dist_finish(reg_handle* h, float T_out[16], reg_result* res) {
     res->converged = mir->converged;
     res->max_iter_reached = mir->max_iter_reached;
     res->rank_last = mir->rank_last;
+    for (int k = 0; k < 6; ++k) {
+        res->localizable[k] = h->prm.use_xicp ? mir->localizable[k] : 1;
+        res->xicp_combined[k] = mir->xicp_comb[k];
+        res->xicp_high[k] = mir->xicp_high[k];
+    }
+    res->n_constraints = h->prm.use_xicp ? mir->n_constraints : 0;
     fill_result(h, mir->sums, res);
     if (mir->status != REG_OK) {
         h->err = "ErrorMinimizer: no point to minimize";

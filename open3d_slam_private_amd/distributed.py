@@ -117,6 +117,13 @@ class StreamDistributedRegistration:
         dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.hist = torch.as_tensor(_DevArray(hist_ptr, (3, 2048), "<i4"), device=dev)
         self.sums = torch.as_tensor(_DevArray(sums_ptr, (32,), "<f8"), device=dev)
+        # R8x (use_xicp): two more small all-reduces, on the first iteration only
+        self.use_xicp = bool(getattr(getattr(reg, "params", None), "use_xicp", 0))
+        self._xicp_first = False
+        if self.use_xicp:
+            cp, sp = reg.dist_xicp_buffers()
+            self.x_center = torch.as_tensor(_DevArray(cp, (4,), "<f8"), device=dev)
+            self.x_sums = torch.as_tensor(_DevArray(sp, (12,), "<f8"), device=dev)
         if all_reduce is not None:
             self._ar = all_reduce
         elif dist is not None and dist.get_world_size() > 1:
@@ -124,9 +131,21 @@ class StreamDistributedRegistration:
         else:
             self._ar = lambda t: None
 
+    def _xicp_analysis(self):
+        """First iteration with use_xicp: phase 4 only stashed the eigen-directions; collect the analysis sums over
+        all ranks, then let every rank decide, solve and update identically (phase 9)."""
+        reg = self.reg
+        reg.dist_phase(7)
+        self._ar(self.x_center)
+        reg.dist_phase(8)
+        self._ar(self.x_sums)
+        reg.dist_phase(9)
+        self._xicp_first = False
+
     def run(self, T_start=None):
         reg = self.reg
         reg.dist_begin(T_start)
+        self._xicp_first = self.use_xicp
         for _ in range(self.iters):
             reg.dist_phase(0)
             if self.use_trimmed:
@@ -138,6 +157,8 @@ class StreamDistributedRegistration:
             reg.dist_phase(3)
             self._ar(self.sums)
             reg.dist_phase(4)
+            if self._xicp_first:
+                self._xicp_analysis()
         return reg.dist_finish()
 
 
@@ -179,6 +200,8 @@ class FusedStreamDistributedRegistration(StreamDistributedRegistration):
         reg.dist_phase(3)
         self._ar(self.sums)
         reg.dist_phase(4)
+        if self._xicp_first:
+            self._xicp_analysis()
         self.n_generic += 1
 
     def _fused(self):
@@ -190,6 +213,7 @@ class FusedStreamDistributedRegistration(StreamDistributedRegistration):
     def run(self, T_start=None):
         reg = self.reg
         reg.dist_begin(T_start)
+        self._xicp_first = self.use_xicp
         limit = self.iters
         generic_left = 2 if self.trimming else 1
         acked = 0          # sequences (1 per enqueued iteration) accounted for: reported or known no-ops
