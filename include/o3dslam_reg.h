@@ -225,6 +225,16 @@ typedef struct {
 REG_API reg_status reg_dist_fused_buffers(reg_handle* h, int n_ranks, int rank, void** contrib, void** gathered,
                                           int64_t* contrib_bytes);
 REG_API reg_status reg_dist_poll(reg_handle* h, reg_dist_status* out);
+/* What the update kernel of ONE specific sequence reported (seq_rel = 1 for the first iteration enqueued after
+   reg_dist_begin): sequences_done == seq_rel when available, 0 otherwise; stream_idle (sampled first) tells that it will
+   never come (update kernels that find the loop done or stalled do not report).  Multi-GPU drivers must steer by these
+   records only: they are identical on every rank, whereas "the latest state seen" depends on timing. */
+REG_API reg_status reg_dist_record(reg_handle* h, int64_t seq_rel, reg_dist_status* out);
+/* Select-by-gather form of the trimmed iteration (fewer dependent collectives): phase 10 (match), all-gather the
+   n_max floats at *d2_local of every rank into *d2_all (n_ranks x n_max), phase 11 (exact 3-level select on the
+   gathered distances, redundantly on every rank; linearize of the local slice; partial sums), all-reduce the 32 sums,
+   phase 4.  n_max >= every rank's reading size (the tail is padded with +inf).  Call after reg_set_source. */
+REG_API reg_status reg_dist_gather_buffers(reg_handle* h, int n_ranks, int64_t n_max, void** d2_local, void** d2_all);
 /* use_xicp on the distributed path: on the FIRST iteration, after phase 4, run phase 7, all-reduce (sum) the 4 doubles at
    *center, phase 8, all-reduce the 12 doubles at *sums, phase 9 (reports with the sequence number of phase 4). */
 REG_API reg_status reg_dist_xicp_buffers(reg_handle* h, void** center, void** sums);

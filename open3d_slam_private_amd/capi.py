@@ -74,7 +74,8 @@ EXPORTS = ["reg_default_params", "reg_shipped_params", "reg_create", "reg_destro
            "reg_solve_update", "reg_host_solve6", "reg_host_x_to_T", "reg_host_centroid", "reg_get_target_info", "reg_profile_kernels", "reg_source_centroid_sums", "reg_prepare_centroid", "reg_compose",
            "reg_dist_begin", "reg_dist_buffers", "reg_dist_phase", "reg_dist_finish",
            "reg_dist_fused_buffers", "reg_dist_poll", "reg_estimate_normals", "reg_host_solve6_xicp",
-           "reg_set_target_f64", "reg_get_target_source_indices", "reg_voxelize_within_volume", "reg_carve_indices", "reg_dist_xicp_buffers"]
+           "reg_set_target_f64", "reg_get_target_source_indices", "reg_voxelize_within_volume", "reg_carve_indices", "reg_dist_xicp_buffers", "reg_dist_gather_buffers",
+           "reg_dist_record"]
 
 
 def lib_path() -> str:
@@ -146,7 +147,9 @@ def load_library():
     lib.reg_dist_finish.argtypes = [vp, f32p, C.POINTER(RegResult)]
     lib.reg_dist_fused_buffers.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int64)]
     lib.reg_dist_poll.argtypes = [vp, C.POINTER(DistStatus)]
+    lib.reg_dist_record.argtypes = [vp, i64, C.POINTER(DistStatus)]
     lib.reg_dist_xicp_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    lib.reg_dist_gather_buffers.argtypes = [vp, C.c_int, i64, C.POINTER(vp), C.POINTER(vp)]
     lib.reg_estimate_normals.argtypes = [vp, vp, i64, i64, C.c_int, C.c_int, C.c_float, vp, C.c_int, vp, vp, vp, vp,
                                          C.POINTER(C.c_int64)]
     for name in EXPORTS:
@@ -442,6 +445,12 @@ class Registration:
     def dist_begin(self, T_start=None):
         self._check(self._lib.reg_dist_begin(self._h, _ptr(_T_in(T_start)) if T_start is not None else None))
 
+    def dist_gather_buffers(self, n_ranks, n_max):
+        """(d2_local_ptr, d2_all_ptr) of the select-by-gather iteration: n_max and n_ranks * n_max float32."""
+        lp, ap = C.c_void_p(), C.c_void_p()
+        self._check(self._lib.reg_dist_gather_buffers(self._h, int(n_ranks), int(n_max), C.byref(lp), C.byref(ap)))
+        return lp.value, ap.value
+
     def dist_xicp_buffers(self):
         """(center_ptr, sums_ptr): 4 and 12 float64 to all-reduce after phases 7 and 8 of the first iteration."""
         cp, sp = C.c_void_p(), C.c_void_p()
@@ -463,6 +472,12 @@ class Registration:
     def dist_poll(self):
         st = DistStatus()
         self._check(self._lib.reg_dist_poll(self._h, C.byref(st)))
+        return st
+
+    def dist_record(self, seq_rel):
+        """Report of ONE specific sequence (1-based since dist_begin); .sequences_done == seq_rel when available."""
+        st = DistStatus()
+        self._check(self._lib.reg_dist_record(self._h, int(seq_rel), C.byref(st)))
         return st
 
     def dist_phase(self, phase):

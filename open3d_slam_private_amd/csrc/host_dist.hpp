@@ -177,6 +177,38 @@ reg_status reg_dist_fused_buffers(reg_handle* h, int n_ranks, int rank, void** c
     return REG_OK;
 }
 
+// Select-by-gather variant of the trimmed iteration: instead of three dependent histogram all-reduces, every rank
+// all-gathers the squared match distances (n_max floats per rank, +inf padded) and runs the exact 3-level select on
+// the gathered array redundantly -- the same kernels on the same multiset of values as the single-GPU path, hence the
+// same limit, with ONE collective in front of the sums all-reduce instead of three.
+//   phase 10: match            -> all-gather d2_local (n_max floats) into d2_all (n_ranks * n_max floats)
+//   phase 11: select on d2_all + linearize of the local slice + partial sums   -> all-reduce the 32 sums -> phase 4
+reg_status reg_dist_gather_buffers(reg_handle* h, int n_ranks, int64_t n_max, void** d2_local, void** d2_all) {
+    if (!h || !d2_local || !d2_all || n_ranks < 1 || n_ranks > 64) return REG_BAD_ARGUMENT;
+    if (h->n == 0) return REG_NOT_CONFIGURED;
+    if (n_max < h->n) {
+        h->err = "reg_dist_gather_buffers: n_max is smaller than this rank's reading";
+        return REG_BAD_ARGUMENT;
+    }
+    HIPCHK(h, hipSetDevice(h->prm.device));
+    if (h->i_d2.cap < (size_t)n_max * 4) {
+        if (h->have_match) {
+            h->err = "reg_dist_gather_buffers: call it right after reg_set_source (the distance buffer cannot grow once "
+                     "matches exist)";
+            return REG_BAD_ARGUMENT;
+        }
+        HIPCHK(h, h->i_d2.reserve((size_t)n_max * 4));
+    }
+    if (n_max > h->n)   // padding: +inf is "no match" for the select kernels
+        HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)(h->i_d2.as<float>() + h->n), 0x7f800000, (size_t)(n_max - h->n), h->stream));
+    HIPCHK(h, h->d_d2all.reserve((size_t)n_ranks * n_max * 4));
+    h->dist_nmax = n_max;
+    h->dist_gather_ranks = n_ranks;
+    *d2_local = h->i_d2.p;
+    *d2_all = h->d_d2all.p;
+    return REG_OK;
+}
+
 // Non-blocking view of the mirror the update kernel writes (the stream-ordered drivers steer by it).
 reg_status reg_dist_poll(reg_handle* h, reg_dist_status* out) {
     if (!h || !out) return REG_BAD_ARGUMENT;
@@ -191,6 +223,31 @@ reg_status reg_dist_poll(reg_handle* h, reg_dist_status* out) {
     out->limit_last = any ? mir->limit_last : INFINITY;
     out->limit_prev = any ? mir->limit_prev : INFINITY;
     out->stream_idle = hipStreamQuery(h->stream) == hipSuccess ? 1 : 0;
+    return REG_OK;
+}
+
+// The record of ONE specific sequence (1 = the first iteration enqueued after reg_dist_begin).  out->sequences_done is
+// set to seq_rel when that update kernel has reported, to 0 when it has not (yet, or ever: update kernels that find the
+// loop done or stalled do not report -- out->stream_idle then tells "never").
+reg_status reg_dist_record(reg_handle* h, int64_t seq_rel, reg_dist_status* out) {
+    if (!h || !out || seq_rel < 1) return REG_BAD_ARGUMENT;
+    const unsigned long long want = h->dist_seq0 + (unsigned long long)seq_rel;
+    // idle must be sampled BEFORE the record: "idle and no record" then really means the kernel did not report
+    const int idle = hipStreamQuery(h->stream) == hipSuccess ? 1 : 0;
+    const HostMirror::SeqRecord* rec = &h->h_mirror->ring[want % kSeqRing];
+    const unsigned long long got = __atomic_load_n(&rec->seq, __ATOMIC_ACQUIRE);
+    std::memset(out, 0, sizeof(*out));
+    out->sequences_enqueued = (int64_t)(h->seq - h->dist_seq0);
+    out->stream_idle = idle;
+    out->limit_last = out->limit_prev = INFINITY;
+    if (got == want) {
+        out->sequences_done = seq_rel;
+        out->iterations = rec->iterations;
+        out->done = rec->done;
+        out->stall = rec->stall;
+        out->limit_last = rec->limit_last;
+        out->limit_prev = rec->limit_prev;
+    }
     return REG_OK;
 }
 
@@ -265,6 +322,30 @@ reg_status reg_dist_phase(reg_handle* h, int phase) {
                                                        nullptr, h->i_w.as<float>(), nullptr, h->d_gathered.as<float>(),
                                                        h->dist_ranks, h->dist_rank, nullptr);
             break;
+        case 10:
+            s = enqueue_match(h);
+            if (s != REG_OK) return s;
+            break;
+        case 11: {
+            if (h->prm.cost != REG_COST_P2PL || h->dist_nmax <= 0) return REG_BAD_ARGUMENT;
+            if (trim) {
+                const int64_t n_all = (int64_t)h->dist_gather_ranks * h->dist_nmax;
+                const float* d2_all = h->d_d2all.as<float>();
+                const int gb = (int)std::min<int64_t>(128, (n_all + 255) / 256);
+                k_hist_level0<<<gb, 256, 0, h->stream>>>(d2_all, n_all, h->shift0, hist0, it);
+                k_select_level<<<gb, 256, 0, h->stream>>>(d2_all, n_all, 1, h->shift0, h->prm.trim_ratio, hist0, hist0 + 2048,
+                                                          nullptr, st, it);
+                k_select_level<<<gb, 256, 0, h->stream>>>(d2_all, n_all, 2, h->shift0, h->prm.trim_ratio, hist0 + 2048,
+                                                          hist0 + 4096, hist0, st, it);
+            }
+            const FilterCfg f = make_filter_cfg(h, h->prm.use_trimmed ? 2 : 0);
+            k_linearize_p2pl<<<h->n_blocks, 256, 0, h->stream>>>(
+                h->s_xyz.as<float4>(), h->has_snrm ? h->s_nrm.as<float4>() : nullptr, h->n, it, h->i_pos.as<int>(),
+                h->i_d2.as<float>(), h->t_pts.as<float4>(), h->t_nrm.as<float4>(), f, st, hist0 + 4096, hist0 + 2048,
+                h->shift0, h->prm.use_xicp ? h->i_w.as<float>() : nullptr, h->i_partials.as<double>());
+            k_partials_sum<<<1, 1024, 0, h->stream>>>(h->i_partials.as<double>(), h->n_blocks, h->i_sums.as<double>(), it);
+            break;
+        }
         // R8x on the distributed path, first iteration only: after phase 4 (which then only stashes the eigen-directions)
         //   7: this rank's share of the matched-point centre   -> caller all-reduces the 4 doubles of reg_dist_xicp_buffers
         //   8: this rank's share of the 12 information sums    -> caller all-reduces them

@@ -44,6 +44,9 @@ struct reg_handle {
     int64_t crop_kept = 0;
     DevBuf v_fout, v_oout, v_oxyz, v_onrm, v_ocov;   // reg_voxelize_within_volume
     DevBuf v_ukeys, v_ustart;                        // reg_carve_indices
+    DevBuf d_d2all;                                  // select-by-gather (multi-GPU): all ranks' squared distances
+    int64_t dist_nmax = 0;
+    int dist_gather_ranks = 0;
     bool xicp_pending = false;     // the next generic iteration is followed by the analysis kernels
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_iter = nullptr;
     bool iter_copy_pending = false;
@@ -199,7 +202,7 @@ void reg_destroy(reg_handle* h) {
     if (h->normals_ws) reg_destroy(h->normals_ws);
     h->n_out.release();
     h->i_xicp.release();
-    for (DevBuf* b : {&h->c_in_xyz, &h->c_in_nrm, &h->c_in_cov, &h->c_flags, &h->c_offs, &h->c_xyz, &h->c_nrm, &h->c_cov, &h->c_idx, &h->v_fout, &h->v_oout, &h->v_oxyz, &h->v_onrm, &h->v_ocov, &h->v_ukeys, &h->v_ustart}) b->release();
+    for (DevBuf* b : {&h->c_in_xyz, &h->c_in_nrm, &h->c_in_cov, &h->c_flags, &h->c_offs, &h->c_xyz, &h->c_nrm, &h->c_cov, &h->c_idx, &h->v_fout, &h->v_oout, &h->v_oxyz, &h->v_onrm, &h->v_ocov, &h->v_ukeys, &h->v_ustart, &h->d_d2all}) b->release();
     h->n_eig.release();
     h->n_cov.release();
     h->n_ids.release();

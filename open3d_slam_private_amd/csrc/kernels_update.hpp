@@ -154,7 +154,14 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
                 host->band_count = (int)s_band_count;
                 host->iterations = sit->iterations;
                 host->done = 0;
+                HostMirror::SeqRecord* rec = &host->ring[seq % kSeqRing];
+                rec->iterations = sit->iterations;
+                rec->done = 0;
+                rec->stall = 1;
+                rec->limit_last = sit->limit_last;
+                rec->limit_prev = sit->limit_prev;
                 __threadfence_system();
+                __hip_atomic_store(&rec->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
                 __hip_atomic_store(&host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
             return;
@@ -541,6 +548,17 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
     constexpr int kMirrorWords = (int)(offsetof(HostMirror, seq) / 4);
     uint32_t* hw = reinterpret_cast<uint32_t*>(host);
     for (int w = lane; w < kMirrorWords; w += 64) hw[w] = mir_w[w];
+    if (lane == 0) {
+        HostMirror::SeqRecord* rec = &host->ring[seq % kSeqRing];
+        const HostMirror* m = reinterpret_cast<const HostMirror*>(mir_w);
+        rec->iterations = m->iterations;
+        rec->done = m->done;
+        rec->stall = 0;
+        rec->limit_last = m->limit_last;
+        rec->limit_prev = m->limit_prev;
+        __threadfence_system();
+        __hip_atomic_store(&rec->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     __threadfence_system();
     if (lane == 0) __hip_atomic_store(&host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }

@@ -58,7 +58,16 @@ struct HostMirror {
     double xicp_comb[6], xicp_high[6];
     unsigned long long stamps[8];   // s_memtime stamps of the update kernel (diagnostics only; nothing reads them)
     unsigned long long seq;
+    // Per-sequence records (ring of kSeqRing): what the update kernel with sequence number s reported.  The multi-GPU
+    // drivers steer ONLY by the record of a specific sequence -- identical on every rank -- never by "whatever has
+    // arrived so far", which depends on timing and would let ranks enqueue different collectives.
+    struct SeqRecord {
+        unsigned long long seq;
+        int iterations, done, stall, pad;
+        float limit_last, limit_prev;
+    } ring[16];
 };
+constexpr int kSeqRing = 16;
 
 // XCD-aware workgroup order: the dispatcher deals workgroups round-robin over the 8 XCDs (blockIdx % 8
 // shares an XCD).  With a Morton-ordered reading, giving each XCD ONE contiguous eighth of the reading means

@@ -170,10 +170,25 @@ class FusedStreamDistributedRegistration(StreamDistributedRegistration):
     update kernel writes (reg_dist_poll) and stays at most `ahead` iterations ahead of it."""
 
     def __init__(self, reg, use_trimmed, trim_ratio, iters, world, rank, dist=None, device=None, all_reduce=None,
-                 all_gather=None, ahead=3, fixed=True, settle_tol=0.25):
+                 all_gather=None, ahead=3, fixed=True, settle_tol=0.25, gather_select=True, n_max=None):
         super().__init__(reg, use_trimmed, iters, dist=dist, device=device, all_reduce=all_reduce)
         import torch
         self.world, self.rank, self.ahead, self.fixed, self.settle_tol = world, rank, ahead, fixed, settle_tol
+        # select-by-gather: ONE all-gather of the squared distances instead of three dependent histogram all-reduces
+        # per select-based iteration (every rank then runs the exact select on the same multiset of values)
+        self.gather_select = bool(gather_select) and bool(use_trimmed)
+        if self.gather_select:
+            if n_max is None:
+                n_max = int(reg.n_source)
+                if dist is not None and world > 1:
+                    t = torch.tensor([n_max], dtype=torch.int64,
+                                     device=device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    n_max = int(t.item())
+            gdev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+            lp, ap = reg.dist_gather_buffers(world, n_max)
+            self.d2_local = torch.as_tensor(_DevArray(lp, (n_max,), "<f4"), device=gdev)
+            self.d2_all = torch.as_tensor(_DevArray(ap, (world * n_max,), "<f4"), device=gdev)
         self.trimming = bool(use_trimmed) and float(np.float32(trim_ratio)) != 1.0
         cp, gp, nbytes = reg.dist_fused_buffers(world, rank)
         dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -190,14 +205,19 @@ class FusedStreamDistributedRegistration(StreamDistributedRegistration):
 
     def _generic(self):
         reg = self.reg
-        reg.dist_phase(0)
-        if self.use_trimmed:
-            self._ar(self.hist[0])
-            reg.dist_phase(1)
-            self._ar(self.hist[1])
-            reg.dist_phase(2)
-            self._ar(self.hist[2])
-        reg.dist_phase(3)
+        if self.gather_select:
+            reg.dist_phase(10)
+            self._ag(self.d2_all, self.d2_local)
+            reg.dist_phase(11)
+        else:
+            reg.dist_phase(0)
+            if self.use_trimmed:
+                self._ar(self.hist[0])
+                reg.dist_phase(1)
+                self._ar(self.hist[1])
+                reg.dist_phase(2)
+                self._ar(self.hist[2])
+            reg.dist_phase(3)
         self._ar(self.sums)
         reg.dist_phase(4)
         if self._xicp_first:
@@ -210,50 +230,75 @@ class FusedStreamDistributedRegistration(StreamDistributedRegistration):
         self.reg.dist_phase(6)
         self.n_fused += 1
 
+    def _record(self, seq_rel):
+        """Blocks until sequence `seq_rel` has reported (returns its record) or can no longer report because the stream
+        drained without it (returns None: an earlier sequence ended or stalled the loop)."""
+        reg = self.reg
+        while True:
+            st = reg.dist_record(seq_rel)
+            if int(st.sequences_done) == seq_rel:
+                return st
+            if st.stream_idle:
+                st = reg.dist_record(seq_rel)          # the report may have landed between the two reads
+                return st if int(st.sequences_done) == seq_rel else None
+
+    def _settled(self, rec):
+        if not self.trimming:
+            return True
+        return (rec is not None and math.isfinite(rec.limit_prev) and math.isfinite(rec.limit_last) and
+                abs(rec.limit_last - rec.limit_prev) <= self.settle_tol * rec.limit_last)
+
     def run(self, T_start=None):
+        """Every decision (select-based or fused iteration, stop, repair) is taken from the record of ONE specific
+        sequence -- the second to last enqueued -- which is the same on every rank; nothing depends on how far the
+        device happens to be when the host looks.  Ranks therefore always enqueue the same collectives."""
         reg = self.reg
         reg.dist_begin(T_start)
         self._xicp_first = self.use_xicp
         limit = self.iters
+        enq = 0            # sequences enqueued since dist_begin
+        base_it = 0        # iterations completed at the last repair point ...
+        base_seq = 0       # ... and the sequence count at that point
         generic_left = 2 if self.trimming else 1
-        acked = 0          # sequences (1 per enqueued iteration) accounted for: reported or known no-ops
-        enq = 0
         while True:
-            st = reg.dist_poll()
-            done_seq = int(st.sequences_done)
-            if done_seq > 0 and st.done:
+            planned = base_it + (enq - base_seq)       # iterations completed once everything enqueued has run
+            rec = None
+            if enq - base_seq >= 2:
+                rec = self._record(enq - 1)             # the second to last sequence
+                if rec is None or rec.stall:
+                    # an earlier sequence stalled (band misprediction) or ended the loop: drain, look at the outcome
+                    while not reg.dist_poll().stream_idle:
+                        pass
+                    top = reg.dist_poll()
+                    if top.done:
+                        break
+                    base_it, base_seq = int(top.iterations), enq
+                    generic_left = 2
+                    self.n_stalls += 1
+                    continue
+                if rec.done:
+                    break
+            if planned >= limit:
+                # everything is enqueued: wait for the last report (or a stall in the burst)
+                last = self._record(enq) if enq > base_seq else None
+                if enq > base_seq and (last is None or last.stall):
+                    while not reg.dist_poll().stream_idle:
+                        pass
+                    top = reg.dist_poll()
+                    if top.done or int(top.iterations) >= limit:
+                        break
+                    base_it, base_seq = int(top.iterations), enq
+                    generic_left = 2
+                    self.n_stalls += 1
+                    continue
                 break
-            if done_seq > 0 and st.stall and done_seq > acked:
-                # the band prediction failed at sequence `done_seq`: what is enqueued behind it are no-ops
-                while not reg.dist_poll().stream_idle:
-                    pass
-                acked = enq
-                generic_left = 2
-                self.n_stalls += 1
-                continue
-            acked = max(acked, done_seq)
-            completed = int(st.iterations) if done_seq > 0 else 0
-            inflight = enq - acked
-            if completed + inflight < limit and inflight < self.ahead:
-                settled = True
-                if self.trimming:
-                    settled = (done_seq > 0 and math.isfinite(st.limit_prev) and math.isfinite(st.limit_last) and
-                               abs(st.limit_last - st.limit_prev) <= self.settle_tol * st.limit_last)
-                if generic_left > 0 or not settled:
-                    self._generic()
-                    generic_left = max(generic_left - 1, 0)
+            if generic_left > 0 or not self._settled(rec):
+                self._generic()
+                generic_left = max(generic_left - 1, 0)
+                enq += 1
+            else:
+                burst = (limit - planned) if self.fixed else 1
+                for _ in range(max(burst, 1)):
+                    self._fused()
                     enq += 1
-                else:
-                    # fixed iteration count: nothing the host could learn changes what has to run -> submit the whole
-                    # rest in one burst (trickle-feeding costs ~6 us per iteration at every kernel boundary);
-                    # a failed band prediction turns what follows into no-ops and is repaired above
-                    burst = (limit - (completed + inflight)) if self.fixed else 1
-                    for _ in range(max(burst, 1)):
-                        self._fused()
-                        enq += 1
-                continue
-            if inflight == 0:
-                break
-            if st.stream_idle and int(reg.dist_poll().sequences_done) <= acked:
-                acked = enq    # drained without a report: no-ops after `done`
         return reg.dist_finish()
