@@ -1,0 +1,137 @@
+"""CPU test of the multi-GPU steering logic (open3d_slam_private_amd/distributed.py): the driver must take every
+decision from the record of ONE specific sequence, so that ranks which observe the device at different moments still
+enqueue exactly the same kernels and collectives.  A simulated device replays a scripted registration (limits per
+iteration, stalls, convergence); its reports become visible to the "host" after a random number of polls."""
+import math
+import random
+from types import SimpleNamespace
+
+import pytest
+
+from open3d_slam_private_amd.distributed import FusedStreamDistributedRegistration
+
+
+class SimDevice:
+    """Stream-ordered model of what the kernels do: every enqueued sequence is executed in order; a sequence reports
+    (becomes a record) unless the loop is done or stalled when it runs, exactly like k_reduce_update."""
+
+    def __init__(self, limits, stall_at=(), done_after=None, max_delay=0, seed=0):
+        self.limits = limits                  # limit_last after iteration j (1-based index j)
+        self.stall_at = set(stall_at)         # fused sequences whose band verification fails
+        self.done_after = done_after          # iterations after which the checkers stop the loop (None: never)
+        self.rng = random.Random(seed)
+        self.max_delay = max_delay
+        self.queue = []                       # enqueued (seq, kind)
+        self.records = {}                     # seq -> record
+        self.visible_after = {}               # seq -> polls still to wait
+        self.iterations, self.done, self.stall = 0, 0, 0
+        self.executed = 0
+        self.top = None
+
+    def enqueue(self, kind):
+        self.queue.append((len(self.queue) + 1, kind))
+
+    def _execute_all(self):
+        while self.executed < len(self.queue):
+            seq, kind = self.queue[self.executed]
+            self.executed += 1
+            if self.done:
+                continue
+            if kind == "fused" and self.stall:
+                continue                                   # no-op behind a stall
+            if kind == "fused" and seq in self.stall_at:
+                self.stall = 1
+                rec = SimpleNamespace(sequences_done=seq, iterations=self.iterations, done=0, stall=1,
+                                      limit_last=self._lim(self.iterations), limit_prev=self._lim(self.iterations - 1),
+                                      stream_idle=0)
+            else:
+                self.stall = 0                             # the select-based iteration repairs
+                self.iterations += 1
+                if self.done_after is not None and self.iterations >= self.done_after:
+                    self.done = 1
+                rec = SimpleNamespace(sequences_done=seq, iterations=self.iterations, done=self.done, stall=0,
+                                      limit_last=self._lim(self.iterations), limit_prev=self._lim(self.iterations - 1),
+                                      stream_idle=0)
+            self.records[seq] = rec
+            self.top = rec
+            self.visible_after[seq] = self.rng.randint(0, self.max_delay)
+
+    def _lim(self, j):
+        return self.limits[min(j, len(self.limits) - 1)] if j >= 1 else math.inf
+
+    # --- the slice of capi.Registration the driver uses ---
+    def dist_begin(self, T):
+        pass
+
+    def dist_record(self, seq):
+        self._execute_all()
+        idle = all(v <= 0 for v in self.visible_after.values())
+        rec = self.records.get(seq)
+        if rec is not None and self.visible_after[seq] <= 0:
+            return SimpleNamespace(**{**rec.__dict__, "stream_idle": int(idle)})
+        for k in self.visible_after:                       # time passes: reports trickle in
+            self.visible_after[k] -= 1
+        return SimpleNamespace(sequences_done=0, iterations=0, done=0, stall=0, limit_last=math.inf,
+                               limit_prev=math.inf, stream_idle=int(idle))
+
+    def dist_poll(self):
+        self._execute_all()
+        for k in self.visible_after:
+            self.visible_after[k] -= 1
+        idle = all(v <= 0 for v in self.visible_after.values())
+        t = self.top
+        if t is None:
+            return SimpleNamespace(sequences_done=0, iterations=0, done=0, stall=0, stream_idle=int(idle),
+                                   limit_last=math.inf, limit_prev=math.inf)
+        return SimpleNamespace(**{**t.__dict__, "stream_idle": int(idle)})
+
+    def dist_finish(self):
+        self._execute_all()
+        return self.iterations, list(self.queue)
+
+
+class Driver(FusedStreamDistributedRegistration):
+    def __init__(self, dev, iters, fixed, trimming=True):          # no device buffers in the simulation
+        self.reg, self.iters, self.fixed = dev, iters, fixed
+        self.trimming, self.settle_tol = trimming, 0.25
+        self.use_xicp = self._xicp_first = False
+        self.n_fused = self.n_generic = self.n_stalls = 0
+
+    def _generic(self):
+        self.reg.enqueue("generic")
+        self.n_generic += 1
+
+    def _fused(self):
+        self.reg.enqueue("fused")
+        self.n_fused += 1
+
+
+LIMITS = [0.11, 0.028, 0.0028, 0.0023, 0.00229, 0.002294, 0.0022941] + [0.00229] * 40
+
+
+@pytest.mark.parametrize("fixed,stalls,done_after", [
+    (True, (), None), (True, (9,), None), (True, (8, 14), None), (False, (), 11), (False, (10,), 14),
+])
+def test_ranks_with_different_timing_enqueue_the_same_sequence(fixed, stalls, done_after):
+    iters = 20 if fixed else 30
+    outs = []
+    for seed, delay in ((0, 0), (1, 3), (2, 7), (3, 25)):
+        dev = SimDevice(LIMITS, stall_at=stalls, done_after=done_after, max_delay=delay, seed=seed)
+        its, queue = Driver(dev, iters, fixed).run()
+        outs.append((its, [k for _, k in queue]))
+    for its, kinds in outs[1:]:
+        assert kinds == outs[0][1], "ranks would have enqueued different collectives"
+        assert its == outs[0][0]
+    its, kinds = outs[0]
+    assert its == (iters if fixed else done_after)
+    assert kinds[0] == "generic" and kinds[1] == "generic" and "fused" in kinds
+    if fixed and not stalls:
+        assert len(kinds) == iters                       # nothing wasted without stalls
+    if not fixed:
+        assert len(kinds) <= done_after + 1              # at most one sequence enqueued past convergence
+
+
+def test_untrimmed_chain_goes_fused_from_the_second_iteration():
+    dev = SimDevice([math.inf] * 50, max_delay=5, seed=4)
+    its, queue = Driver(dev, 12, True, trimming=False).run()
+    assert its == 12 and [k for _, k in queue] == ["generic"] + ["fused"] * 11
