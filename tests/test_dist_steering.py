@@ -128,7 +128,8 @@ def test_ranks_with_different_timing_enqueue_the_same_sequence(fixed, stalls, do
     if fixed and not stalls:
         assert len(kinds) == iters                       # nothing wasted without stalls
     if not fixed:
-        assert len(kinds) <= done_after + 1              # at most one sequence enqueued past convergence
+        # at most one sequence enqueued past convergence, plus the stalled sequence and the one behind it per stall
+        assert len(kinds) <= done_after + 1 + 2 * len(stalls)
 
 
 def test_untrimmed_chain_goes_fused_from_the_second_iteration():
