@@ -520,6 +520,19 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
     }
     HIPCHK(h, hipGetLastError());
     rmark("loop timed");
+    if (getenv("O3D_HINTS")) {
+        // diagnostics: at which radius level did the searches of the LAST iteration end (0 = halo, l + 1 = level l)
+        std::vector<uint8_t> hv((size_t)h->n);
+        if (hipMemcpy(hv.data(), h->i_hint.p, (size_t)h->n, hipMemcpyDeviceToHost) == hipSuccess) {
+            long long cnt[18] = {0};
+            for (uint8_t v : hv) ++cnt[v < 17 ? v : 17];
+            fprintf(stderr, "[o3dreg] terminating level of the last iteration (halo, then levels with rho =");
+            for (int l = 0; l < h->grid.n_levels; ++l) fprintf(stderr, " %.3f", h->grid.rho[l]);
+            fprintf(stderr, "):");
+            for (int l = 0; l <= h->grid.n_levels; ++l) fprintf(stderr, " %lld", cnt[l]);
+            fprintf(stderr, "\n");
+        }
+    }
     if (getenv("O3D_STAMPS")) {
         fprintf(stderr, "update kernel stamps (cycles): reduce %llu [rows %llu select %llu band-add %llu] solve %llu update+check %llu mirror %llu\n", mir->stamps[0],
                 mir->stamps[4], mir->stamps[5], mir->stamps[6], mir->stamps[1], mir->stamps[2], mir->stamps[3]);
