@@ -81,8 +81,8 @@ k_iter_fused(const float4* __restrict__ src, const float4* __restrict__ src_nrm,
         const float3 p = xf_point(T, s.x, s.y, s.z);
         const int hv = hint ? (int)hint[q] : 0;
         int lvl;
-        const Best b = nearest_group<G>(g, p, sub, hv >= 2 ? hv - 2 : -1, &lvl,
-                                        seg_lds + (threadIdx.x / G) * kSegWords<G>);
+        const Best b = nearest_group<G>(g, p, sub, -1, &lvl, seg_lds + (threadIdx.x / G) * kSegWords<G>,
+                                        hv >= 2 ? hv - 2 : -1);
         float vals[kSums];
 #pragma unroll
         for (int k = 0; k < kSums; ++k) vals[k] = 0.f;

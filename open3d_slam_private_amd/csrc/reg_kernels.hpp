@@ -402,8 +402,9 @@ __device__ __forceinline__ void scan_level_wide(const Grid& g, const float3 p, i
     }
 }
 
-// `sub` = lane index inside the group (0..7); `first_level` lets the caller skip radii that were too
-// small for this query in the previous iteration (any starting level is exact).  Returns the level at
+// `sub` = lane index inside the group (0..7); `first_level` < 0 tries the halo level first; `after_halo` is the regular
+// level to continue at when the halo level cannot answer (the previous iteration's terminating level minus one: radii
+// that were too small then are skipped; any starting level is exact).  Returns the level at
 // which the search terminated through *level_out.
 //
 // A box is cut into row segments (one per (brick, y, z): a contiguous run of sorted points).  Phase 1:
@@ -412,7 +413,7 @@ __device__ __forceinline__ void scan_level_wide(const Grid& g, const float3 p, i
 // 16-byte records, i.e. one or two cache lines per group step instead of one line per lane.
 template <int G>
 __device__ __forceinline__ Best nearest_group(const Grid& g, float3 p, int sub, int first_level, int* level_out,
-                                              uint32_t* seg = nullptr) {
+                                              uint32_t* seg = nullptr, int after_halo = -1) {
     Best best;
     best.d2 = INFINITY;
     best.idx = 0xffffffffu;
@@ -445,10 +446,16 @@ __device__ __forceinline__ Best nearest_group(const Grid& g, float3 p, int sub, 
                 return best;
             }
             if (best.pos >= 0 && best.idx == 0xffffffffu) best.idx = __float_as_uint(g.pts[best.pos].w);
-            l = g.level_after_halo;
+            if (best.pos >= 0) {
+                // the halo run produced a candidate: the first radius that covers it terminates the search
+                l = g.level_after_halo;
+                while (l + 1 < g.n_levels && g.rho[l] * g.rho[l] < best.d2) ++l;
+            } else {
+                l = max(g.level_after_halo, after_halo);
+            }
         }
     }
-    l = max(l, 0);
+    l = max(max(l, after_halo), 0);   // no halo level (or the query lies outside its grid): the hinted level
     for (; l < g.n_levels; ++l) {
         if (seg && g.wide_scan) {
             scan_level_wide<G>(g, p, sub, gbase, l, seg, best);

@@ -8,6 +8,7 @@ sc = synth.make_scene(n_src, n_tgt, seed=int(os.environ.get('SEED', '1236')))
 p = capi.shipped_params(); p.fixed_iters = int(os.environ.get('ITERS', '20'))
 if os.environ.get('CELL'): p.cell_size = float(os.environ['CELL'])
 if os.environ.get('XICP'): p.use_xicp = 1
+if os.environ.get('DBG'): p.debug_flags = int(os.environ['DBG'])
 reg = capi.Registration(p)
 reg.set_target(sc.tgt_xyz, sc.tgt_nrm); reg.set_source(sc.src_xyz, sc.src_nrm)
 ms = []
