@@ -32,7 +32,7 @@ static reg_status prepare_rowmajor(reg_handle* h, const float* T_init_row, const
         h->err = "initial transformation contains non-finite values";
         return REG_BAD_TRANSFORM;
     }
-    const bool ptrace = getenv("O3D_TRACE") != nullptr;
+    const bool ptrace = h->env.trace;
     const auto pt0 = std::chrono::steady_clock::now();
     auto pmark = [&](const char* what) {
         if (ptrace) fprintf(stderr, "[o3dreg] prepare %-18s t=%.1fus\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - pt0).count());
@@ -406,7 +406,7 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
     col_to_row(T_init, Ti);
     const auto t_reg0 = std::chrono::steady_clock::now();
     auto rmark = [&](const char* what) {
-        if (getenv("O3D_TRACE"))
+        if (h->env.trace)
             fprintf(stderr, "[o3dreg] register %-14s t=%.1fus\n", what,
                     std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_reg0).count());
     };
@@ -425,7 +425,7 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
     h->profiling = h->prm.profile_loop != 0;
     // loop_ms: HIP events only when profiling (record + synchronise cost ~20 us of host time per registration);
     // otherwise the host clock around the loop -- the loop ends when the last update kernel's mirror has arrived
-    const bool event_timing = h->profiling || getenv("O3D_EVENT_TIMING") != nullptr;
+    const bool event_timing = h->profiling || h->env.event_timing;
     if (event_timing) HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     const auto t_loop_begin = std::chrono::steady_clock::now();
     rmark("ev0");
@@ -438,11 +438,11 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
     const bool can_fuse = p2pl && h->prm.disable_fused != 1;
     const bool trimming = p2pl && h->prm.use_trimmed && h->prm.trim_ratio != 1.0f;
     const int kGenericFirst = trimming ? 2 : 1;
-    const int kAhead = getenv("O3D_KAHEAD") ? atoi(getenv("O3D_KAHEAD")) : 2;
+    const int kAhead = h->env.lookahead;
     const HostMirror* mir = h->h_mirror;
     int generic_left = kGenericFirst;
-    const bool trace = getenv("O3D_TRACE") != nullptr;
-    const float settle_tol = getenv("O3D_SETTLE") ? (float)atof(getenv("O3D_SETTLE")) : 0.25f;
+    const bool trace = h->env.trace;
+    const float settle_tol = h->env.settle_tol;
     unsigned long long last_traced = 0;
     const auto t_loop0 = std::chrono::steady_clock::now();
     unsigned long long acked = seq0;   // every sequence <= acked has either reported or been a no-op
@@ -488,7 +488,7 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
                 // the registration is submitted in one go (a failed band prediction turns what follows into no-ops
                 // and is repaired above).  Submitting while the device crosses a kernel boundary costs about 6 us per
                 // iteration (measured: rocprofv3 timeline, profiles/), hence no trickle-feeding here.
-                int burst = fixed > 0 && !getenv("O3D_NO_BURST") ? limit - (completed + inflight) : 1;
+                int burst = fixed > 0 && !h->env.no_burst ? limit - (completed + inflight) : 1;
                 for (; burst > 0 && s == REG_OK; --burst) s = enqueue_fused(h, true);
             }
             if (trace) {
@@ -520,7 +520,7 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
     }
     HIPCHK(h, hipGetLastError());
     rmark("loop timed");
-    if (getenv("O3D_HINTS")) {
+    if (h->env.hints) {
         // diagnostics: at which radius level did the searches of the LAST iteration end (0 = halo, l + 1 = level l)
         std::vector<uint8_t> hv((size_t)h->n);
         if (hipMemcpy(hv.data(), h->i_hint.p, (size_t)h->n, hipMemcpyDeviceToHost) == hipSuccess) {
@@ -533,7 +533,7 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
             fprintf(stderr, "\n");
         }
     }
-    if (getenv("O3D_STAMPS")) {
+    if (h->env.stamps) {
         fprintf(stderr, "update kernel stamps (cycles): reduce %llu [rows %llu select %llu band-add %llu] solve %llu update+check %llu mirror %llu\n", mir->stamps[0],
                 mir->stamps[4], mir->stamps[5], mir->stamps[6], mir->stamps[1], mir->stamps[2], mir->stamps[3]);
         fprintf(stderr, "   select detail: verify+stage-issue %llu, zero+hist+barriers %llu, wave0 pick/rank %llu\n", mir->stamps[3], mir->stamps[7] >> 32, mir->stamps[7] & 0xffffffffull);

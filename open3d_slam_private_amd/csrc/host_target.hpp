@@ -30,8 +30,30 @@ struct DevBuf {
     }
 };
 
+// Diagnostic / tuning switches from the environment, read once when the handle is created (tools/ scripts set them;
+// production code leaves them unset).
+struct EnvSwitches {
+    bool trace = false;         // O3D_TRACE: host-side timeline of prepare / enqueue / reports on stderr
+    bool event_timing = false;  // O3D_EVENT_TIMING: loop_ms from HIP events even when not profiling
+    bool no_burst = false;      // O3D_NO_BURST: trickle-feed the fused iterations (A/B of the burst submission)
+    bool hints = false;         // O3D_HINTS: histogram of the terminating search level of the last iteration
+    bool stamps = false;        // O3D_STAMPS: in-kernel cycle stamps of the update kernel
+    int lookahead = 2;          // O3D_KAHEAD
+    float settle_tol = 0.25f;   // O3D_SETTLE
+    void read() {
+        trace = getenv("O3D_TRACE") != nullptr;
+        event_timing = getenv("O3D_EVENT_TIMING") != nullptr;
+        no_burst = getenv("O3D_NO_BURST") != nullptr;
+        hints = getenv("O3D_HINTS") != nullptr;
+        stamps = getenv("O3D_STAMPS") != nullptr;
+        if (const char* v = getenv("O3D_KAHEAD")) lookahead = std::max(1, atoi(v));
+        if (const char* v = getenv("O3D_SETTLE")) settle_tol = (float)atof(v);
+    }
+};
+
 struct reg_handle {
     reg_params prm;
+    EnvSwitches env;
     std::string err;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -168,6 +190,7 @@ reg_status reg_create(const reg_params* p, reg_handle** out) {
     if (p->use_xicp && p->cost != REG_COST_P2PL) return REG_BAD_ARGUMENT;   // the analysis expects point-to-plane (ICP.cpp:1118)
     reg_handle* h = new reg_handle();
     h->prm = *p;
+    h->env.read();
     std::memset(&h->info, 0, sizeof(h->info));
     std::memset(&h->grid, 0, sizeof(h->grid));
     if (hipSetDevice(p->device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {

@@ -9,12 +9,12 @@ p = capi.shipped_params(); p.fixed_iters = int(os.environ.get('ITERS', '20'))
 if os.environ.get('CELL'): p.cell_size = float(os.environ['CELL'])
 if os.environ.get('XICP'): p.use_xicp = 1
 if os.environ.get('DBG'): p.debug_flags = int(os.environ['DBG'])
+if os.environ.get('TRACE_LAST'):
+    os.environ['O3D_TRACE'] = '1'   # switches are read when the handle is created: every registration is traced
 reg = capi.Registration(p)
 reg.set_target(sc.tgt_xyz, sc.tgt_nrm); reg.set_source(sc.src_xyz, sc.src_nrm)
 ms = []
 for r in range(reps):
-    if r == reps - 1 and os.environ.get('TRACE_LAST'):
-        os.environ['O3D_TRACE'] = '1'
     T, res = reg.register(np.eye(4))
     ms.append(res.loop_ms)
 print("localizable", list(res.localizable), "constraints", res.n_constraints)
