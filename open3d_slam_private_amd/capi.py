@@ -246,15 +246,7 @@ class Registration:
         x = np.ascontiguousarray(xyz, np.float64)
         nr = np.ascontiguousarray(normals, np.float64) if normals is not None else None
         cv = np.ascontiguousarray(covs, np.float64).reshape(-1, 9) if covs is not None else None
-        c = None
-        if crop is not None:
-            c = RegCrop()
-            c.type = int(crop.get("type", CROP_NONE))
-            for k in range(3):
-                c.center[k] = float(crop.get("center", (0, 0, 0))[k])
-            c.radius_min = float(crop.get("radius_min", 0.0))
-            c.radius_max = float(crop.get("radius_max", 0.0))
-            c.min_z, c.max_z = float(crop.get("min_z", 0.0)), float(crop.get("max_z", 0.0))
+        c = self._crop_struct(crop)
         kept = C.c_int64(0)
         st = self._lib.reg_set_target_f64(self._h, _ptr(x), _ptr(nr), _ptr(cv), x.shape[0] if x.ndim == 2 else 0, 0,
                                           C.byref(c) if c is not None else None, C.byref(kept))
@@ -264,15 +256,7 @@ class Registration:
 
     def set_target_f64_device(self, xyz_ptr, m, nrm_ptr=None, cov_ptr=None, crop=None):
         """As set_target_f64 with the fp64 cloud already resident in HBM (m x 3 doubles; normals m x 3; covs m x 9)."""
-        c = None
-        if crop is not None:
-            c = RegCrop()
-            c.type = int(crop.get("type", CROP_NONE))
-            for k in range(3):
-                c.center[k] = float(crop.get("center", (0, 0, 0))[k])
-            c.radius_min = float(crop.get("radius_min", 0.0))
-            c.radius_max = float(crop.get("radius_max", 0.0))
-            c.min_z, c.max_z = float(crop.get("min_z", 0.0)), float(crop.get("max_z", 0.0))
+        c = self._crop_struct(crop)
         kept = C.c_int64(0)
         st = self._lib.reg_set_target_f64(self._h, C.c_void_p(xyz_ptr), C.c_void_p(nrm_ptr) if nrm_ptr else None,
                                           C.c_void_p(cov_ptr) if cov_ptr else None, m, 1,
