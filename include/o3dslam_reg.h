@@ -230,6 +230,11 @@ REG_API reg_status reg_dist_poll(reg_handle* h, reg_dist_status* out);
    never come (update kernels that find the loop done or stalled do not report).  Multi-GPU drivers must steer by these
    records only: they are identical on every rank, whereas "the latest state seen" depends on timing. */
 REG_API reg_status reg_dist_record(reg_handle* h, int64_t seq_rel, reg_dist_status* out);
+/* Reading preparation without a host round trip: reg_dist_centroid_sums enqueues this rank's integer centroid sums
+   (numeric contract NC1) and returns their device address (3 x int64); the caller all-reduces (sum) them on the handle's
+   stream; reg_dist_prepare then centres and pre-transforms the slice with the centroid of all n_global reading points. */
+REG_API reg_status reg_dist_centroid_sums(reg_handle* h, void** sums_dev);
+REG_API reg_status reg_dist_prepare(reg_handle* h, const float T_init[16], int64_t n_global);
 /* Select-by-gather form of the trimmed iteration (fewer dependent collectives): phase 10 (match), all-gather the
    n_max floats at *d2_local of every rank into *d2_all (n_ranks x n_max), phase 11 (exact 3-level select on the
    gathered distances, redundantly on every rank; linearize of the local slice; partial sums), all-reduce the 32 sums,

@@ -75,7 +75,7 @@ EXPORTS = ["reg_default_params", "reg_shipped_params", "reg_create", "reg_destro
            "reg_dist_begin", "reg_dist_buffers", "reg_dist_phase", "reg_dist_finish",
            "reg_dist_fused_buffers", "reg_dist_poll", "reg_estimate_normals", "reg_host_solve6_xicp",
            "reg_set_target_f64", "reg_get_target_source_indices", "reg_voxelize_within_volume", "reg_carve_indices", "reg_dist_xicp_buffers", "reg_dist_gather_buffers",
-           "reg_dist_record"]
+           "reg_dist_record", "reg_dist_centroid_sums", "reg_dist_prepare"]
 
 
 def lib_path() -> str:
@@ -148,6 +148,8 @@ def load_library():
     lib.reg_dist_fused_buffers.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int64)]
     lib.reg_dist_poll.argtypes = [vp, C.POINTER(DistStatus)]
     lib.reg_dist_record.argtypes = [vp, i64, C.POINTER(DistStatus)]
+    lib.reg_dist_centroid_sums.argtypes = [vp, C.POINTER(vp)]
+    lib.reg_dist_prepare.argtypes = [vp, f32p, i64]
     lib.reg_dist_xicp_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     lib.reg_dist_gather_buffers.argtypes = [vp, C.c_int, i64, C.POINTER(vp), C.POINTER(vp)]
     lib.reg_estimate_normals.argtypes = [vp, vp, i64, i64, C.c_int, C.c_int, C.c_float, vp, C.c_int, vp, vp, vp, vp,
@@ -457,6 +459,16 @@ class Registration:
         st = DistStatus()
         self._check(self._lib.reg_dist_poll(self._h, C.byref(st)))
         return st
+
+    def dist_centroid_sums(self):
+        """Enqueues this slice's integer centroid sums; returns the device address of the 3 int64 to all-reduce."""
+        p = C.c_void_p()
+        self._check(self._lib.reg_dist_centroid_sums(self._h, C.byref(p)))
+        return p.value
+
+    def dist_prepare(self, T_init, n_global):
+        Ti = _T_in(np.eye(4) if T_init is None else T_init)
+        self._check(self._lib.reg_dist_prepare(self._h, _ptr(Ti), int(n_global)))
 
     def dist_record(self, seq_rel):
         """Report of ONE specific sequence (1-based since dist_begin); .sequences_done == seq_rel when available."""

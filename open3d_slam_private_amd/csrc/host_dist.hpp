@@ -25,6 +25,28 @@ reg_status reg_prepare_centroid(reg_handle* h, const float T_init[16], const flo
     return prepare_rowmajor(h, Tr, c_read);
 }
 
+// Stream-ordered reading preparation for the multi-GPU path (no host round trip): enqueue this rank's integer centroid
+// sums into a device buffer, let the caller all-reduce (sum) those 3 int64 on the same stream, then prepare from them.
+reg_status reg_dist_centroid_sums(reg_handle* h, void** sums_dev) {
+    reg_status s = check_ready(h, false);
+    if (s != REG_OK) return s;
+    if (!sums_dev) return REG_BAD_ARGUMENT;
+    HIPCHK(h, hipSetDevice(h->prm.device));
+    HIPCHK(h, h->s_misc.reserve(256));
+    HIPCHK(h, hipMemsetAsync(h->s_misc.p, 0, 3 * sizeof(unsigned long long), h->stream));
+    const int blocks = (int)std::min<int64_t>(1024, (h->n + 255) / 256);
+    k_centroid_sums<<<blocks, 256, 0, h->stream>>>(h->s_raw.as<float>(), h->s_stride, h->n, h->s_misc.as<unsigned long long>());
+    *sums_dev = h->s_misc.p;   // 3 x int64 (fixed point, 2^16 per unit): sum over ranks = sums of the whole reading
+    return REG_OK;
+}
+
+reg_status reg_dist_prepare(reg_handle* h, const float T_init[16], int64_t n_global) {
+    if (!h || !T_init || n_global < 1) return REG_BAD_ARGUMENT;
+    float Tr[16];
+    col_to_row(T_init, Tr);
+    return prepare_rowmajor(h, Tr, nullptr, n_global);
+}
+
 reg_status reg_compose(reg_handle* h, const float T_iter[16], float T_out[16]) {
     reg_status s = check_ready(h, true);
     if (s != REG_OK) return s;

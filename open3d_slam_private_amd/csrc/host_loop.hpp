@@ -25,7 +25,10 @@ static reg_status check_ready(reg_handle* h, bool need_prepared) {
 }
 
 // R2
-static reg_status prepare_rowmajor(reg_handle* h, const float* T_init_row, const float* c_override = nullptr) {
+// n_global > 0: the centroid sums in s_misc have already been produced (reg_dist_centroid_sums) and reduced over all
+// ranks by the caller; they describe n_global points.
+static reg_status prepare_rowmajor(reg_handle* h, const float* T_init_row, const float* c_override = nullptr,
+                                   int64_t n_global = 0) {
     reg_status s = check_ready(h, false);
     if (s != REG_OK) return s;
     if (!m4_is_finite(T_init_row)) {
@@ -45,7 +48,7 @@ static reg_status prepare_rowmajor(reg_handle* h, const float* T_init_row, const
     // only needed for the final composition (R10), so nothing here waits for the device
     HIPCHK(h, h->s_misc.reserve(256));
     HIPCHK(h, h->s_prep.reserve(sizeof(PrepState)));
-    if (p2pl && !c_override) {
+    if (p2pl && !c_override && n_global <= 0) {
         HIPCHK(h, hipMemsetAsync(h->s_misc.p, 0, 3 * sizeof(unsigned long long), h->stream));
         const int blocks = (int)std::min<int64_t>(1024, (n + 255) / 256);
         k_centroid_sums<<<blocks, 256, 0, h->stream>>>(h->s_raw.as<float>(), h->s_stride, n,
@@ -54,7 +57,7 @@ static reg_status prepare_rowmajor(reg_handle* h, const float* T_init_row, const
     pmark("centroid");
     Xf4 Ti;
     std::memcpy(Ti.m, T_init_row, 64);
-    k_make_T0<<<1, 64, 0, h->stream>>>(h->s_misc.as<unsigned long long>(), n,
+    k_make_T0<<<1, 64, 0, h->stream>>>(h->s_misc.as<unsigned long long>(), n_global > 0 ? n_global : n,
                                        make_float3(h->c_ref[0], h->c_ref[1], h->c_ref[2]), Ti, p2pl ? 1 : 0,
                                        c_override ? 1 : 0,
                                        c_override ? make_float3(c_override[0], c_override[1], c_override[2])

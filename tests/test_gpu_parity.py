@@ -731,10 +731,13 @@ def test_select_by_gather_iteration_two_uneven_slices_one_gpu():
         r.set_target(sc.tgt_xyz, sc.tgt_nrm)
         r.set_source(sc.src_xyz[lo:hi], sc.src_nrm[lo:hi])
         halves.append(r)
-    sums = sum(r.source_centroid_sums() for r in halves)
-    c = (sums.astype(np.float64) / (65536.0 * n)).astype(np.float32)
+    # stream-ordered preparation: integer centroid sums stay on the device, "all-reduced" there, no host round trip
+    cents = [torch.as_tensor(_DevArray(r.dist_centroid_sums(), (3,), "<i8"), device=dev) for r in halves]
+    tot = cents[0] + cents[1]
+    for cnt in cents:
+        cnt.copy_(tot)
     for r in halves:
-        r.prepare_centroid(np.eye(4), c)
+        r.dist_prepare(np.eye(4), n)
         lp, ap = r.dist_gather_buffers(2, n_max)
         _, sp = r.dist_buffers()
         bufs.append((torch.as_tensor(_DevArray(lp, (n_max,), "<f4"), device=dev),
