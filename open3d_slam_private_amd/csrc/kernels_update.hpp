@@ -548,19 +548,20 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
     constexpr int kMirrorWords = (int)(offsetof(HostMirror, seq) / 4);
     uint32_t* hw = reinterpret_cast<uint32_t*>(host);
     for (int w = lane; w < kMirrorWords; w += 64) hw[w] = mir_w[w];
+    HostMirror::SeqRecord* srec = &host->ring[seq % kSeqRing];
     if (lane == 0) {
-        HostMirror::SeqRecord* rec = &host->ring[seq % kSeqRing];
         const HostMirror* m = reinterpret_cast<const HostMirror*>(mir_w);
-        rec->iterations = m->iterations;
-        rec->done = m->done;
-        rec->stall = 0;
-        rec->limit_last = m->limit_last;
-        rec->limit_prev = m->limit_prev;
-        __threadfence_system();
-        __hip_atomic_store(&rec->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        srec->iterations = m->iterations;
+        srec->done = m->done;
+        srec->stall = 0;
+        srec->limit_last = m->limit_last;
+        srec->limit_prev = m->limit_prev;
     }
-    __threadfence_system();
-    if (lane == 0) __hip_atomic_store(&host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();   // one fence for the mirror words and the record; then the two sequence words
+    if (lane == 0) {
+        __hip_atomic_store(&srec->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // Stream-ordered distributed path: this rank's workgroup partials -> 32 doubles (summed over ranks by the caller's
