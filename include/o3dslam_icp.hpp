@@ -134,8 +134,11 @@ public:
     SurfaceNormalFilter(const SurfaceNormalFilter&) = delete;
     SurfaceNormalFilter& operator=(const SurfaceNormalFilter&) = delete;
 
+    // optional outputs by the reference's descriptor names: eigValues 3xN (ascending), matchedIds knn x N, densities N,
+    // meanDists N, eigVectors 9xN; covariances6 {xx xy xz yy yz zz} for the GICP operator
     void compute(const DataPointsView& cloud, float* normals, float* eigValues = nullptr, int32_t* matchedIds = nullptr,
-                 float* covariances6 = nullptr, bool regularisedCovariances = false) {
+                 float* covariances6 = nullptr, bool regularisedCovariances = false, float* densities = nullptr,
+                 float* meanDists = nullptr, float* eigVectors = nullptr) {
         if (!h_) {
             reg_params p;
             reg_default_params(&p);
@@ -147,11 +150,18 @@ public:
             }
         }
         if (cloud.getNbPoints() == 0) throw std::runtime_error("The point cloud is empty.");
+        reg_normals_out out{};
+        out.normals = normals;
+        out.eigvals = eigValues;
+        out.covs = covariances6;
+        out.ids = matchedIds;
+        out.densities = densities;
+        out.mean_dists = meanDists;
+        out.eigvecs = eigVectors;
         const reg_status s = reg_estimate_normals(h_, cloud.features, cloud.feature_stride, cloud.n,
                                                   cloud.on_device ? 1 : 0, (int)knn, maxDist,
                                                   orientTowardsViewpoint ? viewpoint.data() : nullptr,
-                                                  regularisedCovariances ? 1 : 0, normals, eigValues, covariances6,
-                                                  matchedIds, nullptr);
+                                                  regularisedCovariances ? 1 : 0, &out, nullptr);
         if (s == REG_BAD_ARGUMENT) throw InvalidParameter(reg_last_error(h_));
         if (s == REG_DEVICE_ERROR) throw DeviceError(reg_last_error(h_));
         if (s != REG_OK) throw std::runtime_error(reg_last_error(h_));

@@ -268,16 +268,31 @@ REG_API reg_status reg_profile_kernels(reg_handle* h, const float T_iter[16], in
      open3d_slam/src/helpers.cpp:153-165           (the same with a radius cap).
    xyz: n points, stride in floats.  k in [1,32] neighbours (the point itself counts), max_dist > 0 (may be +inf).
    viewpoint: NULL -> sign such that the largest component is positive; else normals face the viewpoint.
-   Outputs (host pointers, or device pointers when on_device != 0), indexed like the input:
-     normals  n x 3 (required);  eigvals n x 3 ascending (may be NULL);
-     covs     n x 6 {xx xy xz yy yz zz} (may be NULL): C/m, or with regularise != 0 the plane-like GICP covariance
-              V diag(1e-3,1,1) V^T (small_gicp / Open3D GICP convention);
-     ids      n x k neighbour indices ascending by (d2, index), -1 padded (may be NULL).
+   Outputs (host pointers, or device pointers when on_device != 0), indexed like the input; every member but `normals`
+   may be NULL (the names in brackets are the filter's keep* switches / descriptor names, SurfaceNormal.h:71-77):
+     normals    n x 3                                                   [keepNormals, "normals"]
+     eigvals    n x 3 ascending                                          [keepEigenValues + sortEigen, "eigValues"]
+     eigvecs    n x 9: eigenvector k (ascending eigenvalue) at [9 i + 3 k + r]   [keepEigenVectors, "eigVectors"]
+     covs       n x 6 {xx xy xz yy yz zz}: C/m, or with regularise != 0 the plane-like GICP covariance
+                V diag(1e-3,1,1) V^T (small_gicp / Open3D GICP convention)
+     densities  n: m / (4/3 pi r^3), r = largest distance of a neighbour from the neighbourhood mean (utils.h:106-128);
+                0 for a degenerate neighbourhood                        [keepDensities, "densities"]
+     mean_dists n: |p - mean| (SurfaceNormal.cpp:243-252); (float)SIZE_MAX when degenerate   [keepMeanDist, "meanDists"]
+     ids        n x k neighbour indices ascending by (d2, index), -1 padded   [keepMatchedIds, "matchedIds"]
    n_rescanned (may be NULL): points whose candidate list exceeded the on-chip list (statistics; results are exact). */
+typedef struct {
+    float*   normals;
+    float*   eigvals;
+    float*   eigvecs;
+    float*   covs;
+    float*   densities;
+    float*   mean_dists;
+    int32_t* ids;
+} reg_normals_out;
 REG_API reg_status reg_estimate_normals(reg_handle* h, const float* xyz, int64_t xyz_stride, int64_t n, int on_device,
                                         int k, float max_dist, const float viewpoint[3], int regularise,
-                                        float* normals, float* eigvals, float* covs, int32_t* ids,
-                                        int64_t* n_rescanned);
+                                        const reg_normals_out* out, int64_t* n_rescanned);
+
 
 /* ---- next row: target-side preparation on the device ------------------------------------------
    Replaces, in front of reg_set_target, what the mapper does on the host every referenceCloudSettingPeriod_:

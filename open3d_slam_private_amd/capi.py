@@ -48,6 +48,10 @@ class RegResult(C.Structure):
                 ("xicp_combined", C.c_double * 6), ("xicp_high", C.c_double * 6)]
 
 
+class NormalsOut(C.Structure):
+    _fields_ = [(name, C.c_void_p) for name in ("normals", "eigvals", "eigvecs", "covs", "densities", "mean_dists", "ids")]
+
+
 class RegCrop(C.Structure):
     _fields_ = [("type", C.c_int32), ("reserved", C.c_int32), ("center", C.c_double * 3), ("radius_min", C.c_double),
                 ("radius_max", C.c_double), ("min_z", C.c_double), ("max_z", C.c_double)]
@@ -152,8 +156,8 @@ def load_library():
     lib.reg_dist_prepare.argtypes = [vp, f32p, i64]
     lib.reg_dist_xicp_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     lib.reg_dist_gather_buffers.argtypes = [vp, C.c_int, i64, C.POINTER(vp), C.POINTER(vp)]
-    lib.reg_estimate_normals.argtypes = [vp, vp, i64, i64, C.c_int, C.c_int, C.c_float, vp, C.c_int, vp, vp, vp, vp,
-                                         C.POINTER(C.c_int64)]
+    lib.reg_estimate_normals.argtypes = [vp, vp, i64, i64, C.c_int, C.c_int, C.c_float, vp, C.c_int,
+                                         C.POINTER(NormalsOut), C.POINTER(C.c_int64)]
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError if the library does not export what the header declares
     _lib = lib
@@ -328,35 +332,41 @@ class Registration:
         self.n_source = n
 
     def estimate_normals(self, xyz, k=10, max_dist=np.inf, viewpoint=None, regularise=False, want_eigvals=False,
-                         want_covs=False, want_ids=False):
+                         want_covs=False, want_ids=False, want_eigvecs=False, want_densities=False,
+                         want_mean_dists=False):
         """Exact k-NN + PCA normals (SurfaceNormal.cpp:152-252 / CloudRegistration.cpp:25-43).  Returns a dict with
-        `normals` (n,3) and, on request, `eigvals` (n,3), `covs` (n,6), `ids` (n,k), plus `n_rescanned`."""
+        `normals` (n,3) and, on request, `eigvals` (n,3), `eigvecs` (n,9), `covs` (n,6), `densities` (n,),
+        `mean_dists` (n,), `ids` (n,k), plus `n_rescanned`."""
         xyz = _f32(xyz)
         n = xyz.shape[0] if xyz.ndim == 2 else 0
         out = {"normals": np.zeros((n, 3), np.float32)}
-        if want_eigvals:
-            out["eigvals"] = np.zeros((n, 3), np.float32)
-        if want_covs:
-            out["covs"] = np.zeros((n, 6), np.float32)
-        if want_ids:
-            out["ids"] = np.zeros((n, k), np.int32)
+        for key, want, shape, dt in (("eigvals", want_eigvals, (n, 3), np.float32), ("eigvecs", want_eigvecs, (n, 9), np.float32),
+                                     ("covs", want_covs, (n, 6), np.float32), ("densities", want_densities, (n,), np.float32),
+                                     ("mean_dists", want_mean_dists, (n,), np.float32), ("ids", want_ids, (n, k), np.int32)):
+            if want:
+                out[key] = np.zeros(shape, dt)
+        o = NormalsOut()
+        for key in ("normals", "eigvals", "eigvecs", "covs", "densities", "mean_dists", "ids"):
+            setattr(o, key, out[key].ctypes.data if key in out else None)
         vp_ = _f32(viewpoint) if viewpoint is not None else None
         resc = C.c_int64(0)
         self._check(self._lib.reg_estimate_normals(
             self._h, _ptr(xyz), xyz.shape[1] if xyz.ndim == 2 else 3, n, 0, int(k), float(max_dist), _ptr(vp_),
-            1 if regularise else 0, _ptr(out["normals"]), _ptr(out.get("eigvals")), _ptr(out.get("covs")),
-            _ptr(out.get("ids")), C.byref(resc)))
+            1 if regularise else 0, C.byref(o), C.byref(resc)))
         out["n_rescanned"] = int(resc.value)
         return out
 
     def estimate_normals_device(self, xyz_ptr, xyz_stride, n, normals_ptr, k=10, max_dist=np.inf, viewpoint=None,
-                                regularise=False, eigvals_ptr=None, covs_ptr=None, ids_ptr=None):
+                                regularise=False, eigvals_ptr=None, covs_ptr=None, ids_ptr=None, eigvecs_ptr=None,
+                                densities_ptr=None, mean_dists_ptr=None):
         vp_ = _f32(viewpoint) if viewpoint is not None else None
+        o = NormalsOut()
+        o.normals, o.eigvals, o.eigvecs, o.covs = normals_ptr, eigvals_ptr, eigvecs_ptr, covs_ptr
+        o.densities, o.mean_dists, o.ids = densities_ptr, mean_dists_ptr, ids_ptr
         resc = C.c_int64(0)
         self._check(self._lib.reg_estimate_normals(
             self._h, C.c_void_p(xyz_ptr), xyz_stride, n, 1, int(k), float(max_dist), _ptr(vp_), 1 if regularise else 0,
-            C.c_void_p(normals_ptr), C.c_void_p(eigvals_ptr) if eigvals_ptr else None,
-            C.c_void_p(covs_ptr) if covs_ptr else None, C.c_void_p(ids_ptr) if ids_ptr else None, C.byref(resc)))
+            C.byref(o), C.byref(resc)))
         return int(resc.value)
 
     # ---- device-pointer entry points (inputs already resident in HBM) ---------------------------

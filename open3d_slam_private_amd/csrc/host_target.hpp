@@ -60,7 +60,7 @@ struct reg_handle {
     bool device_ok = false;   // false: reg_create could not get a HIP device (every entry point then fails loudly)
     bool structure_only = false;   // workspace handle of reg_estimate_normals: bin table only, no attributes
     reg_handle* normals_ws = nullptr;
-    DevBuf n_out, n_eig, n_cov, n_ids;
+    DevBuf n_out, n_eig, n_cov, n_ids, n_extra;
     DevBuf i_xicp;                 // XicpState (R8x first-iteration analysis)
     DevBuf c_in_xyz, c_in_nrm, c_in_cov, c_flags, c_offs, c_xyz, c_nrm, c_cov, c_idx;   // reg_set_target_f64
     int64_t crop_kept = 0;
@@ -229,6 +229,7 @@ void reg_destroy(reg_handle* h) {
     h->n_eig.release();
     h->n_cov.release();
     h->n_ids.release();
+    h->n_extra.release();
     DevBuf* bufs[] = {&h->t_raw, &h->t_nrm_raw, &h->t_cov_raw, &h->t_centred, &h->t_keys, &h->t_keys2, &h->t_vals,
                       &h->t_vals2, &h->t_pts, &h->t_nrm, &h->t_cov, &h->t_flags, &h->t_scan, &h->t_hash, &h->t_cells,
                       &h->t_tmp, &h->t_misc, &h->t_dir, &h->s_raw, &h->s_nrm_raw, &h->s_cov_raw, &h->s_xyz, &h->s_nrm, &h->s_cov,
@@ -968,9 +969,12 @@ reg_status reg_carve_indices(reg_handle* h, const double* map_xyz, const double*
 }
 
 reg_status reg_estimate_normals(reg_handle* h, const float* xyz, int64_t xyz_stride, int64_t n, int on_device, int k,
-                                float max_dist, const float* viewpoint, int regularise, float* normals, float* eigvals,
-                                float* covs, int32_t* ids, int64_t* n_rescanned) {
+                                float max_dist, const float* viewpoint, int regularise, const reg_normals_out* out,
+                                int64_t* n_rescanned) {
     if (!h) return REG_BAD_ARGUMENT;
+    if (!out) return REG_BAD_ARGUMENT;
+    float *normals = out->normals, *eigvals = out->eigvals, *covs = out->covs;
+    int32_t* ids = out->ids;
     if (!h->device_ok) return REG_DEVICE_ERROR;
     if (!xyz || xyz_stride < 3 || !normals || k < 1 || k > kPcaMaxK || !(max_dist > 0.f) || n > 0x7fffffffLL) {
         h->err = "reg_estimate_normals: bad argument (1 <= k <= 32, max_dist > 0, normals != NULL)";
@@ -1009,7 +1013,7 @@ reg_status reg_estimate_normals(reg_handle* h, const float* xyz, int64_t xyz_str
     while (start < w->grid.n_levels - 1 && w->grid.rho[start] < need) ++start;
     const float* d_raw = on_device ? xyz : w->t_raw.as<float>();
     HIPCHK(h, hipSetDevice(h->prm.device));
-    float *d_n = normals, *d_e = eigvals, *d_c = covs;
+    float *d_n = normals, *d_e = eigvals, *d_c = covs, *d_v = out->eigvecs, *d_d = out->densities, *d_m = out->mean_dists;
     int32_t* d_i = ids;
     if (!on_device) {
         HIPCHK(h, h->n_out.reserve((size_t)n * 12));
@@ -1026,13 +1030,20 @@ reg_status reg_estimate_normals(reg_handle* h, const float* xyz, int64_t xyz_str
             HIPCHK(h, h->n_ids.reserve((size_t)n * k * 4));
             d_i = h->n_ids.as<int32_t>();
         }
+        if (out->eigvecs || out->densities || out->mean_dists) {
+            HIPCHK(h, h->n_extra.reserve((size_t)n * (9 + 1 + 1) * 4));
+            float* base = h->n_extra.as<float>();
+            if (out->eigvecs) d_v = base;
+            if (out->densities) d_d = base + (size_t)n * 9;
+            if (out->mean_dists) d_m = base + (size_t)n * 10;
+        }
     }
     HIPCHK(h, w->t_misc.reserve(256));
     HIPCHK(h, hipMemsetAsync(w->t_misc.p, 0, 4, h->stream));
     const float vp[3] = {viewpoint ? viewpoint[0] : 0.f, viewpoint ? viewpoint[1] : 0.f, viewpoint ? viewpoint[2] : 0.f};
     const int64_t blocks = (n + (256 / kPcaGroup) - 1) / (256 / kPcaGroup);
     k_knn_pca<<<(unsigned)blocks, 256, 0, h->stream>>>(w->grid, d_raw, xyz_stride, n, k, start, vp[0], vp[1], vp[2], viewpoint ? 1 : 0,
-                                                       regularise, d_n, d_e, d_c, d_i, w->t_misc.as<uint32_t>());
+                                                       regularise, d_n, d_e, d_c, d_i, w->t_misc.as<uint32_t>(), d_v, d_d, d_m);
     uint32_t resc = 0;
     HIPCHK(h, hipMemcpyAsync(&resc, w->t_misc.p, 4, hipMemcpyDeviceToHost, h->stream));
     if (!on_device) {
@@ -1040,6 +1051,9 @@ reg_status reg_estimate_normals(reg_handle* h, const float* xyz, int64_t xyz_str
         if (eigvals) HIPCHK(h, hipMemcpyAsync(eigvals, d_e, (size_t)n * 12, hipMemcpyDeviceToHost, h->stream));
         if (covs) HIPCHK(h, hipMemcpyAsync(covs, d_c, (size_t)n * 24, hipMemcpyDeviceToHost, h->stream));
         if (ids) HIPCHK(h, hipMemcpyAsync(ids, d_i, (size_t)n * k * 4, hipMemcpyDeviceToHost, h->stream));
+        if (out->eigvecs) HIPCHK(h, hipMemcpyAsync(out->eigvecs, d_v, (size_t)n * 36, hipMemcpyDeviceToHost, h->stream));
+        if (out->densities) HIPCHK(h, hipMemcpyAsync(out->densities, d_d, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+        if (out->mean_dists) HIPCHK(h, hipMemcpyAsync(out->mean_dists, d_m, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());

@@ -72,7 +72,8 @@ __device__ __forceinline__ void pca_scan_box(const Grid& g, const float3 p, int 
 __global__ void __launch_bounds__(256)
 k_knn_pca(Grid g, const float* __restrict__ raw_xyz, int64_t raw_stride, int64_t n, int k, int start_level, float vx,
           float vy, float vz, int has_vp, int regularise, float* __restrict__ normals, float* __restrict__ eigvals,
-          float* __restrict__ covs, int32_t* __restrict__ ids_out, uint32_t* __restrict__ n_overflow) {
+          float* __restrict__ covs, int32_t* __restrict__ ids_out, uint32_t* __restrict__ n_overflow,
+          float* __restrict__ eigvecs, float* __restrict__ densities, float* __restrict__ mean_dists) {
     constexpr int GP = 256 / kPcaGroup;   // points per workgroup
     __shared__ float l_d2[GP][kPcaCap];
     __shared__ uint32_t l_idx[GP][kPcaCap];
@@ -224,10 +225,50 @@ k_knn_pca(Grid g, const float* __restrict__ raw_xyz, int64_t raw_stride, int64_t
     normals[3 * oi + 0] = nv[0];
     normals[3 * oi + 1] = nv[1];
     normals[3 * oi + 2] = nv[2];
+    const bool degenerate = !(m >= 3 && rank + 1 >= 3);
     if (eigvals) {
         eigvals[3 * oi + 0] = (float)lam[o0];
         eigvals[3 * oi + 1] = (float)lam[o1];
         eigvals[3 * oi + 2] = (float)lam[o2];
+    }
+    if (eigvecs) {   // "eigVectors": eigenvector k (ascending eigenvalue), components contiguous; zero when degenerate
+        const int oo[3] = {o0, o1, o2};
+        for (int kk = 0; kk < 3; ++kk)
+            for (int a = 0; a < 3; ++a) eigvecs[9 * oi + 3 * kk + a] = degenerate ? 0.f : (float)V[a * 3 + oo[kk]];
+    }
+    if (densities) {   // utils.h:106-128: m / (4/3 pi r^3), r^2 = largest squared distance of a neighbour from the mean
+        float dens = 0.f;
+        if (!degenerate) {
+            float mx = 0.f;
+            for (int r = 0; r < m; ++r) {
+                const float dx = nb_xyz[grp][r][0] - mean[0], dy = nb_xyz[grp][r][1] - mean[1], dz = nb_xyz[grp][r][2] - mean[2];
+                float u = dx * dx;
+                float v2 = dy * dy;
+                float s2 = u + v2;
+                u = dz * dz;
+                s2 = s2 + u;
+                mx = fmaxf(mx, s2);
+            }
+            const float tq = (float)(4. / 3.), pi = (float)3.14159265358979323846;
+            const float c0 = tq * pi;
+            const float r3 = mx * sqrtf(mx);
+            const float volume = c0 * r3;
+            dens = volume > 0.f ? (float)m / volume : 0.f;
+        }
+        densities[oi] = dens;
+    }
+    if (mean_dists) {   // SurfaceNormal.cpp:243-252
+        float md = 18446744073709551615.0f;   // (float)std::numeric_limits<std::size_t>::max()
+        if (!degenerate) {
+            const float dx = p.x - mean[0], dy = p.y - mean[1], dz = p.z - mean[2];
+            float u = dx * dx;
+            float v2 = dy * dy;
+            float s2 = u + v2;
+            u = dz * dz;
+            s2 = s2 + u;
+            md = sqrtf(s2);
+        }
+        mean_dists[oi] = md;
     }
     if (covs) {
         double Cn[9];

@@ -215,8 +215,8 @@ class SurfaceNormalDataPointsFilter:
     device: parameters by the reference's names; `epsilon` must be 0 (the search is exact).  `filter` returns a
     DataPoints with the `normals` descriptor added (keepNormals) and keeps `eigValues` / `matchedIds` on the filter."""
 
-    def __init__(self, knn=5, maxDist=float("inf"), epsilon=0.0, keepNormals=True, keepEigenValues=False,
-                 keepMatchedIds=False, viewpoint=None):
+    def __init__(self, knn=5, maxDist=float("inf"), epsilon=0.0, keepNormals=True, keepDensities=False,
+                 keepEigenValues=False, keepEigenVectors=False, keepMatchedIds=False, keepMeanDist=False, viewpoint=None):
         if knn < 3:
             raise InvalidParameter("knn: minimum 3 (SurfaceNormal.h:68)")
         if knn > 32:
@@ -227,7 +227,8 @@ class SurfaceNormalDataPointsFilter:
             raise InvalidParameter("maxDist: must be > 0")
         self.knn, self.maxDist, self.keepNormals = int(knn), float(maxDist), keepNormals
         self.keepEigenValues, self.keepMatchedIds, self.viewpoint = keepEigenValues, keepMatchedIds, viewpoint
-        self.eigValues = self.matchedIds = None
+        self.keepDensities, self.keepEigenVectors, self.keepMeanDist = keepDensities, keepEigenVectors, keepMeanDist
+        self.eigValues = self.matchedIds = self.densities = self.eigVectors = self.meanDists = None
         self._reg = None
 
     def filter(self, cloud: DataPoints) -> DataPoints:
@@ -235,10 +236,13 @@ class SurfaceNormalDataPointsFilter:
             self._reg = capi.Registration(capi.default_params())
         try:
             out = self._reg.estimate_normals(cloud.features, k=self.knn, max_dist=self.maxDist, viewpoint=self.viewpoint,
-                                             want_eigvals=self.keepEigenValues, want_ids=self.keepMatchedIds)
+                                             want_eigvals=self.keepEigenValues, want_ids=self.keepMatchedIds,
+                                             want_densities=self.keepDensities, want_eigvecs=self.keepEigenVectors,
+                                             want_mean_dists=self.keepMeanDist)
         except RegError as e:
             raise _translate(e) from None
         self.eigValues, self.matchedIds = out.get("eigvals"), out.get("ids")
+        self.densities, self.eigVectors, self.meanDists = out.get("densities"), out.get("eigvecs"), out.get("mean_dists")
         return DataPoints(cloud.features, out["normals"] if self.keepNormals else cloud.normals, cloud.covariances)
 
 

@@ -1346,7 +1346,7 @@ ORC_API void orc_knn_k(const void* tree, const float* q_xyz, int64_t stride, int
    Numeric contract: mean and C accumulated in fp32 sequentially in neighbour order; eigen-decomposition in fp64. */
 ORC_API void orc_surface_normals(const float* xyz, int64_t stride, int64_t n, int k, float max_dist,
                                  const float* viewpoint, int regularise, float* normals, float* eigvals, float* covs,
-                                 int32_t* ids_out, int n_threads) {
+                                 int32_t* ids_out, int n_threads, float* eigvecs, float* densities, float* mean_dists) {
     void* tree = orc_kd_build(xyz, stride, n);
     int32_t* ids = (int32_t*)malloc((size_t)n * k * 4);
     float* d2 = (float*)malloc((size_t)n * k * 4);
@@ -1405,8 +1405,45 @@ ORC_API void orc_surface_normals(const float* xyz, int64_t stride, int64_t n, in
             }
         }
         for (int a = 0; a < 3; ++a) normals[3 * i + a] = nv[a];
+        const int degenerate = !(m >= 3 && rank + 1 >= 3);
         if (eigvals)
             for (int a = 0; a < 3; ++a) eigvals[3 * i + a] = (float)lam[o[a]];
+        if (eigvecs) /* keepEigenVectors: eigenvector kk (ascending eigenvalue), zero when degenerate */
+            for (int kk = 0; kk < 3; ++kk)
+                for (int a = 0; a < 3; ++a) eigvecs[9 * i + 3 * kk + a] = degenerate ? 0.f : (float)V[a * 3 + o[kk]];
+        if (densities) { /* DataPointsFilters/utils/utils.h:106-128 */
+            float dens = 0.f;
+            if (!degenerate) {
+                float mx = 0.f;
+                for (int j = 0; j < m; ++j) {
+                    const float* q = xyz + (int64_t)ids[i * k + j] * stride;
+                    float dx = q[0] - mean[0], dy = q[1] - mean[1], dz = q[2] - mean[2];
+                    float u = dx * dx, v2 = dy * dy;
+                    float s2 = u + v2;
+                    u = dz * dz;
+                    s2 = s2 + u;
+                    if (s2 > mx) mx = s2;
+                }
+                const float tq = (float)(4. / 3.), pi = (float)3.14159265358979323846;
+                const float c0 = tq * pi;
+                const float r3 = mx * sqrtf(mx);
+                const float volume = c0 * r3;
+                dens = volume > 0.f ? (float)m / volume : 0.f;
+            }
+            densities[i] = dens;
+        }
+        if (mean_dists) { /* SurfaceNormal.cpp:243-252 */
+            float md = 18446744073709551615.0f;
+            if (!degenerate) {
+                float dx = xyz[i * stride] - mean[0], dy = xyz[i * stride + 1] - mean[1], dz = xyz[i * stride + 2] - mean[2];
+                float u = dx * dx, v2 = dy * dy;
+                float s2 = u + v2;
+                u = dz * dz;
+                s2 = s2 + u;
+                md = sqrtf(s2);
+            }
+            mean_dists[i] = md;
+        }
         if (covs) {
             double Cn[9];
             if (regularise) { /* plane-like GICP covariance: V diag(1e-3, 1, 1) V^T */

@@ -249,17 +249,24 @@ def knn_k(tree: "KdTree", q_xyz, k, max_dist=math.inf, n_threads=1):
     return ids, d2
 
 
-def surface_normals(xyz, k, max_dist=math.inf, viewpoint=None, regularise=False, n_threads=1):
-    """(normals n x 3, eigenvalues ascending n x 3, covariances n x 6, neighbour ids n x k)."""
+def surface_normals(xyz, k, max_dist=math.inf, viewpoint=None, regularise=False, n_threads=1, extras=False):
+    """(normals n x 3, eigenvalues ascending n x 3, covariances n x 6, neighbour ids n x k); with extras=True also
+    (eigenvectors n x 9, densities n, mean distances n)."""
     x = _f32(xyz)
     n = x.shape[0]
     nrm = np.empty((n, 3), np.float32)
     ev = np.empty((n, 3), np.float32)
     cov = np.empty((n, 6), np.float32)
     ids = np.empty((n, k), np.int32)
+    evec = np.empty((n, 9), np.float32) if extras else None
+    dens = np.empty(n, np.float32) if extras else None
+    md = np.empty(n, np.float32) if extras else None
     vp = _f32(viewpoint) if viewpoint is not None else None
     lib().orc_surface_normals(_p(x), C.c_int64(x.shape[1]), C.c_int64(n), C.c_int(k), C.c_float(max_dist), _p(vp),
-                              C.c_int(1 if regularise else 0), _p(nrm), _p(ev), _p(cov), _p(ids), C.c_int(n_threads))
+                              C.c_int(1 if regularise else 0), _p(nrm), _p(ev), _p(cov), _p(ids), C.c_int(n_threads),
+                              _p(evec), _p(dens), _p(md))
+    if extras:
+        return nrm, ev, cov, ids, evec, dens, md
     return nrm, ev, cov, ids
 
 

@@ -134,3 +134,31 @@ def test_surface_normal_filter_mirror_by_reference_names():
         SurfaceNormalDataPointsFilter(knn=2)              # SurfaceNormal.h:68: minimum 3
     with pytest.raises(InvalidParameter):
         SurfaceNormalDataPointsFilter(knn=5, epsilon=0.1)
+
+
+def test_densities_eigenvectors_and_mean_distances_match_the_oracle():
+    """The filter's other descriptors (SurfaceNormal.h:72-76): densities (utils.h:106-128), eigVectors, meanDists."""
+    ref = np.load(os.path.join(GOLD, "car_cloud400.npy"))[:, :3]
+    reg = capi.Registration(capi.shipped_params())
+    out = reg.estimate_normals(ref, k=12, max_dist=0.4, want_eigvals=True, want_eigvecs=True, want_densities=True,
+                               want_mean_dists=True, want_ids=True)
+    nrm, ev, cov, ids, evec, dens, md = orc.surface_normals(ref, 12, max_dist=0.4, n_threads=8, extras=True)
+    assert np.array_equal(out["ids"], ids)
+    assert np.allclose(out["densities"], dens, rtol=1e-6, atol=0)
+    assert np.allclose(out["mean_dists"], md, rtol=1e-6, atol=1e-9)
+    V, Vo = out["eigvecs"].reshape(-1, 3, 3), evec.reshape(-1, 3, 3)
+    # eigenvectors up to sign, where the eigenvalues are separated (a repeated eigenvalue has no unique vector)
+    sep = (ev[:, 1] - ev[:, 0] > 1e-3 * ev[:, 2]) & (ev[:, 2] - ev[:, 1] > 1e-3 * ev[:, 2])
+    dots = np.abs(np.sum(V[sep] * Vo[sep], axis=2))
+    assert sep.mean() > 0.5 and np.all(dots > 1 - 1e-4)
+    assert np.allclose(np.abs(np.sum(V[sep][:, 0] * out["normals"][sep], axis=1)), 1.0, atol=1e-5)   # normal = first
+    # degenerate neighbourhoods: density 0, mean distance = (float)SIZE_MAX, zero eigenvectors
+    sparse = np.random.default_rng(2).uniform(-50, 50, size=(200, 3)).astype(np.float32)
+    o2 = reg.estimate_normals(sparse, k=6, max_dist=5.0, want_densities=True, want_mean_dists=True, want_eigvecs=True,
+                              want_ids=True)
+    lonely = (o2["ids"] >= 0).sum(axis=1) < 3
+    assert lonely.any()
+    assert np.all(o2["densities"][lonely] == 0) and np.all(o2["mean_dists"][lonely] == np.float32(18446744073709551615.0))
+    assert np.all(o2["eigvecs"][lonely] == 0)
+    r2 = orc.surface_normals(sparse, 6, max_dist=5.0, extras=True)
+    assert np.array_equal(o2["densities"], r2[5]) and np.array_equal(o2["mean_dists"], r2[6])
