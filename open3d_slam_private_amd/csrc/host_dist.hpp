@@ -244,7 +244,12 @@ reg_status reg_dist_poll(reg_handle* h, reg_dist_status* out) {
     out->stall = any ? mir->stall : 0;
     out->limit_last = any ? mir->limit_last : INFINITY;
     out->limit_prev = any ? mir->limit_prev : INFINITY;
-    out->stream_idle = hipStreamQuery(h->stream) == hipSuccess ? 1 : 0;
+    const hipError_t qe = hipStreamQuery(h->stream);
+    if (qe != hipSuccess && qe != hipErrorNotReady) {
+        h->err = std::string("device fault while waiting for an iteration: ") + hipGetErrorString(qe);
+        return REG_DEVICE_ERROR;
+    }
+    out->stream_idle = qe == hipSuccess ? 1 : 0;
     return REG_OK;
 }
 
@@ -255,7 +260,12 @@ reg_status reg_dist_record(reg_handle* h, int64_t seq_rel, reg_dist_status* out)
     if (!h || !out || seq_rel < 1) return REG_BAD_ARGUMENT;
     const unsigned long long want = h->dist_seq0 + (unsigned long long)seq_rel;
     // idle must be sampled BEFORE the record: "idle and no record" then really means the kernel did not report
-    const int idle = hipStreamQuery(h->stream) == hipSuccess ? 1 : 0;
+    const hipError_t qe = hipStreamQuery(h->stream);
+    if (qe != hipSuccess && qe != hipErrorNotReady) {   // a device fault must end the caller's polling loop
+        h->err = std::string("device fault while waiting for an iteration: ") + hipGetErrorString(qe);
+        return REG_DEVICE_ERROR;
+    }
+    const int idle = qe == hipSuccess ? 1 : 0;
     const HostMirror::SeqRecord* rec = &h->h_mirror->ring[want % kSeqRing];
     const unsigned long long got = __atomic_load_n(&rec->seq, __ATOMIC_ACQUIRE);
     std::memset(out, 0, sizeof(*out));
