@@ -347,6 +347,17 @@ REG_API reg_status reg_carve_indices(reg_handle* h, const double* map_xyz, const
                                      const reg_crop* subset, double voxel_size, double max_ray, double truncation,
                                      double min_dot, int32_t* removed, int64_t* n_removed);
 
+/* B1 result extra: the 6x6 information matrix of a registered pair, as the loop-closure and odometry
+   constraint builders obtain it from open3d::pipelines::registration::GetInformationMatrixFromPointClouds
+   (open3d_slam/src/constraint_builders.cpp:69-73, PlaceRecognition.cpp:148; arithmetic in un-vendored Open3D 0.15.1:
+   PARITY UNPINNED, restated): for every reading point whose nearest reference point q (reference frame) lies within
+   max_dist after applying T, G = [[0, z, -y, 1, 0, 0], [-z, 0, x, 0, 1, 0], [y, -x, 0, 0, 0, 1]] with (x, y, z) = q and
+   info = sum G^T G (rotation-first ordering, row-major 6x6, float64).  max_dist must not exceed the handle's max_dist
+   (the reach of the search structure).  Uses the reference and reading currently set; a prepared reading is
+   re-prepared at T. */
+REG_API reg_status reg_information_matrix(reg_handle* h, const float T[16], float max_dist, double info[36],
+                                         int64_t* n_pairs);
+
 /* Introspection of the search structure (tests, DESIGN.md numbers). */
 typedef struct {
     int64_t n_points;

@@ -79,7 +79,8 @@ EXPORTS = ["reg_default_params", "reg_shipped_params", "reg_create", "reg_destro
            "reg_dist_begin", "reg_dist_buffers", "reg_dist_phase", "reg_dist_finish",
            "reg_dist_fused_buffers", "reg_dist_poll", "reg_estimate_normals", "reg_host_solve6_xicp",
            "reg_set_target_f64", "reg_get_target_source_indices", "reg_voxelize_within_volume", "reg_carve_indices", "reg_dist_xicp_buffers", "reg_dist_gather_buffers",
-           "reg_dist_record", "reg_dist_centroid_sums", "reg_dist_prepare"]
+           "reg_dist_record", "reg_dist_centroid_sums", "reg_dist_prepare",
+           "reg_information_matrix"]
 
 
 def lib_path() -> str:
@@ -154,6 +155,7 @@ def load_library():
     lib.reg_dist_record.argtypes = [vp, i64, C.POINTER(DistStatus)]
     lib.reg_dist_centroid_sums.argtypes = [vp, C.POINTER(vp)]
     lib.reg_dist_prepare.argtypes = [vp, f32p, i64]
+    lib.reg_information_matrix.argtypes = [vp, f32p, C.c_float, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.reg_dist_xicp_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     lib.reg_dist_gather_buffers.argtypes = [vp, C.c_int, i64, C.POINTER(vp), C.POINTER(vp)]
     lib.reg_estimate_normals.argtypes = [vp, vp, i64, i64, C.c_int, C.c_int, C.c_float, vp, C.c_int,
@@ -389,6 +391,14 @@ class Registration:
         self.last_result = res
         self._check(st)
         return _T_out(To), res
+
+    def information_matrix(self, T, max_dist):
+        """GetInformationMatrixFromPointClouds analogue (constraint_builders.cpp:69-73): (6x6 float64, n_pairs)."""
+        Ti = _T_in(T)
+        info = (C.c_double * 36)()
+        n = C.c_int64(0)
+        self._check(self._lib.reg_information_matrix(self._h, _ptr(Ti), float(max_dist), info, C.byref(n)))
+        return np.array(info[:], np.float64).reshape(6, 6), int(n.value)
 
     def prepare(self, T_init=None):
         Ti = _T_in(np.eye(4) if T_init is None else T_init)

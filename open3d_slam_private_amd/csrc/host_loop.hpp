@@ -581,6 +581,51 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
     return REG_OK;
 }
 
+reg_status reg_information_matrix(reg_handle* h, const float T[16], float max_dist, double info[36], int64_t* n_pairs) {
+    if (!h || !T || !info) return REG_BAD_ARGUMENT;
+    if (n_pairs) *n_pairs = 0;
+    if (!(max_dist > 0.f) || max_dist > h->prm.max_dist) {
+        h->err = "reg_information_matrix: max_dist must be positive and within the handle's max_dist";
+        return REG_BAD_ARGUMENT;
+    }
+    float Tr[16];
+    col_to_row(T, Tr);
+    reg_status s = prepare_rowmajor(h, Tr);
+    if (s != REG_OK) return s;
+    const bool p2pl = h->prm.cost == REG_COST_P2PL;
+    float T_start[16];
+    if (p2pl)
+        m4_identity(T_start);
+    else
+        std::memcpy(T_start, Tr, 64);
+    s = init_iter_state(h, T_start, 0);
+    if (s != REG_OK) return s;
+    s = enqueue_match(h, /*zero_hist=*/false);
+    if (s != REG_OK) return s;
+    h->have_match = true;
+    HIPCHK(h, h->i_sums.reserve(kSums * 8));
+    HIPCHK(h, hipMemsetAsync(h->i_sums.p, 0, 10 * sizeof(double), h->stream));
+    const int blocks = (int)std::min<int64_t>(512, (h->n + 255) / 256);
+    k_info_sums<<<blocks, 256, 0, h->stream>>>(h->i_pos.as<int>(), h->i_d2.as<float>(), h->n, h->t_pts.as<float4>(),
+                                               h->c_ref[0], h->c_ref[1], h->c_ref[2], max_dist * max_dist,
+                                               h->i_sums.as<double>());
+    double m[10];
+    HIPCHK(h, hipMemcpyAsync(m, h->i_sums.p, sizeof(m), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    // sum over pairs of G^T G with rows [0 z -y 1 0 0], [-z 0 x 0 1 0], [y -x 0 0 0 1]
+    const double c = m[0], sx = m[1], sy = m[2], sz = m[3], xx = m[4], yy = m[5], zz = m[6], xy = m[7], xz = m[8], yz = m[9];
+    const double I[36] = {yy + zz, -xy, -xz, 0, -sz, sy,
+                          -xy, xx + zz, -yz, sz, 0, -sx,
+                          -xz, -yz, xx + yy, -sy, sx, 0,
+                          0, sz, -sy, c, 0, 0,
+                          -sz, 0, sx, 0, c, 0,
+                          sy, -sx, 0, 0, 0, c};
+    std::memcpy(info, I, sizeof(I));
+    if (n_pairs) *n_pairs = (int64_t)llround(c);
+    return REG_OK;
+}
+
 reg_status reg_compute(reg_handle* h, const float* xyz, int64_t xyz_stride, const float* nrm, int64_t nrm_stride,
                        const float* cov, int64_t n, int on_device, const float T_init[16], float T_out[16],
                        reg_result* res) {

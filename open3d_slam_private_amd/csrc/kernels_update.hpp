@@ -599,3 +599,30 @@ __global__ void k_unpermute_f32(const float* __restrict__ in, int64_t n, const u
     if (i >= n) return;
     out[perm ? (int64_t)perm[i] : i] = in[i];
 }
+
+// Sums behind GetInformationMatrixFromPointClouds: over the matches within max_d2, the moments of the matched reference
+// point in the reference's own frame (sorted point + centroid): count, x, y, z, xx, yy, zz, xy, xz, yz.
+__global__ void __launch_bounds__(256)
+k_info_sums(const int* __restrict__ pos, const float* __restrict__ d2, int64_t n, const float4* __restrict__ tgt,
+            float cx, float cy, float cz, float max_d2, double* __restrict__ out /* [10], zeroed */) {
+    double v[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) v[k] = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int j = pos[i];
+        if (j < 0 || !(d2[i] <= max_d2)) continue;
+        const float4 t = tgt[j];
+        const double x = (double)(t.x + cx), y = (double)(t.y + cy), z = (double)(t.z + cz);
+        v[0] += 1.0;
+        v[1] += x;
+        v[2] += y;
+        v[3] += z;
+        v[4] += x * x;
+        v[5] += y * y;
+        v[6] += z * z;
+        v[7] += x * y;
+        v[8] += x * z;
+        v[9] += y * z;
+    }
+    xicp_block_add<10>(v, out);
+}

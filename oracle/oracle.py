@@ -383,3 +383,17 @@ def carve_indices(map_xyz, scan_xyz, sensor, voxel_size=0.1, max_ray=20.0, trunc
                     remove.add(j)
             dist += voxel_size
     return np.array(sorted(remove), np.int32)
+
+
+def information_matrix(tgt_xyz, src_xyz, T, max_dist):
+    """GetInformationMatrixFromPointClouds as used in open3d_slam/src/constraint_builders.cpp:69-73 (Open3D 0.15.1
+    arithmetic, not in the tree: restated, PARITY UNPINNED): exact NN of every transformed reading point within
+    max_dist; G = [[0,z,-y,1,0,0],[-z,0,x,0,1,0],[y,-x,0,0,0,1]] at the matched reference point; sum G^T G in float64."""
+    tree = KdTree(_f32(tgt_xyz))
+    ids, d2 = tree.knn(_f32(src_xyz), _f32(T), max_dist=max_dist)
+    q = _f32(tgt_xyz)[ids[ids >= 0]].astype(np.float64)
+    info = np.zeros((6, 6))
+    for x, y, z in q:
+        G = np.array([[0, z, -y, 1, 0, 0], [-z, 0, x, 0, 1, 0], [y, -x, 0, 0, 0, 1]], np.float64)
+        info += G.T @ G
+    return info, q.shape[0]

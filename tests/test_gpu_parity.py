@@ -799,3 +799,27 @@ def test_fused_stream_driver_repairs_stalls_and_follows_the_checkers(fixed):
         assert drv.n_stalls >= 1
     else:
         assert res.converged == res_ref.converged and res.max_iter_reached == res_ref.max_iter_reached
+
+
+def test_information_matrix_matches_the_restatement():
+    """B1 result extra: GetInformationMatrixFromPointClouds analogue (constraint_builders.cpp:69-73).
+    Pair count exact; entries within 1e-6 relative of the float64 restatement: the device holds the reference centred
+    (P2PL) and reconstructs q = fl(centred + centroid), one fp32 rounding away from the caller's coordinate (parity
+    unpinned vs Open3D itself)."""
+    sc = synth.make_scene(3000, 40000, seed=61)
+    p = capi.shipped_params()
+    reg = capi.Registration(p)
+    reg.set_target(sc.tgt_xyz, sc.tgt_nrm)
+    reg.set_source(sc.src_xyz, sc.src_nrm)
+    T, _ = reg.register(np.eye(4))
+    for md in (0.12, 0.5):
+        info, n_pairs = reg.information_matrix(T, md)
+        ref, n_ref = orc.information_matrix(sc.tgt_xyz, sc.src_xyz, T, md)
+        assert n_pairs == n_ref and n_pairs > 1000
+        assert np.allclose(info, ref, rtol=1e-6, atol=1e-3)
+        assert np.allclose(info, info.T) and np.all(np.linalg.eigvalsh(info) > 0)
+    with pytest.raises(capi.RegError):
+        reg.information_matrix(T, 0.6)          # beyond the reach of the search structure (max_dist 0.5)
+    # the handle is still good for a registration afterwards
+    T2, _ = reg.register(np.eye(4))
+    assert np.array_equal(T, T2)
