@@ -549,13 +549,16 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
     uint32_t* hw = reinterpret_cast<uint32_t*>(host);
     for (int w = lane; w < kMirrorWords; w += 64) hw[w] = mir_w[w];
     HostMirror::SeqRecord* srec = &host->ring[seq % kSeqRing];
-    if (lane == 0) {
+    {
+        // the record's six payload words in ONE coalesced store (lanes 2..7 of the record's word layout)
         const HostMirror* m = reinterpret_cast<const HostMirror*>(mir_w);
-        srec->iterations = m->iterations;
-        srec->done = m->done;
-        srec->stall = 0;
-        srec->limit_last = m->limit_last;
-        srec->limit_prev = m->limit_prev;
+        static_assert(sizeof(HostMirror::SeqRecord) == 32, "record layout: seq(8) iterations done stall pad limit_last limit_prev");
+        uint32_t word = 0;
+        if (lane == 2) word = (uint32_t)m->iterations;
+        if (lane == 3) word = (uint32_t)m->done;
+        if (lane == 6) word = __float_as_uint(m->limit_last);
+        if (lane == 7) word = __float_as_uint(m->limit_prev);
+        if (lane >= 2 && lane < 8) reinterpret_cast<uint32_t*>(srec)[lane] = word;   // stall = pad = 0
     }
     __threadfence_system();   // one fence for the mirror words and the record; then the two sequence words
     if (lane == 0) {
