@@ -144,6 +144,23 @@ static void prof_mark(reg_handle* h, int kind, bool start) {
     if (start) h->prof_kind.push_back(kind);
 }
 
+// Launch with the kernel's own begin / end timestamps when the loop is being profiled (hipExtLaunchKernelGGL attaches
+// the two events to the dispatch packet itself: the same interval rocprofv3 --kernel-trace reports, without the
+// gaps that events recorded around a launch include).
+template <class K, class... A>
+static void launch_timed(reg_handle* h, int kind, K kernel, dim3 grid, dim3 block, A... args) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (!h->profiling || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        if (e0) (void)hipEventDestroy(e0);
+        hipLaunchKernelGGL(kernel, grid, block, 0, h->stream, args...);
+        return;
+    }
+    hipExtLaunchKernelGGL(kernel, grid, block, 0, h->stream, e0, e1, 0, args...);
+    h->prof_ev.push_back(e0);
+    h->prof_ev.push_back(e1);
+    h->prof_kind.push_back(kind);
+}
+
 static reg_status enqueue_match(reg_handle* h, bool zero_hist = false) {
     const bool trim = h->prm.cost == REG_COST_P2PL && h->prm.use_trimmed;
     if (trim && zero_hist) HIPCHK(h, hipMemsetAsync(h->i_hist.p, 0, 3 * 2048 * 4, h->stream));
@@ -151,30 +168,27 @@ static reg_status enqueue_match(reg_handle* h, bool zero_hist = false) {
     uint32_t* hist0 = (trim && fused_hist) ? h->i_hist.as<uint32_t>() : nullptr;
     uint32_t* hist2 = trim ? h->i_hist.as<uint32_t>() + 4096 : nullptr;
     const IterState* it = h->i_iter.as<IterState>();
-    prof_mark(h, 0, true);
     if (h->prm.match_variant == 1) {
+        prof_mark(h, 0, true);
         k_match<<<h->n_blocks, 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->n, it, h->grid, h->i_pos.as<int>(),
                                                     h->i_d2.as<float>(), hist0, hist2, h->shift0);
+        prof_mark(h, 0, false);
     } else {
         uint8_t* hint = h->prm.match_variant == 2 ? nullptr : h->i_hint.as<uint8_t>();
-        if (h->prm.lanes_per_point == 4) {
-            const int blocks = grid_for(h->n * 4);
-            k_match_g8<4><<<8 * ((blocks + 7) / 8), 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->n, it, h->grid,
-                                                                          h->i_pos.as<int>(), h->i_d2.as<float>(), hist0,
-                                                                          hist2, hint, h->shift0, h->prm.debug_flags, blocks);
-        } else if (h->prm.lanes_per_point == 2) {
-            const int blocks = grid_for(h->n * 2);
-            k_match_g8<2><<<8 * ((blocks + 7) / 8), 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->n, it, h->grid,
-                                                                          h->i_pos.as<int>(), h->i_d2.as<float>(), hist0,
-                                                                          hist2, hint, h->shift0, h->prm.debug_flags, blocks);
-        } else {
-            const int blocks = grid_for(h->n * 8);
-            k_match_g8<8><<<8 * ((blocks + 7) / 8), 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->n, it, h->grid,
-                                                                          h->i_pos.as<int>(), h->i_d2.as<float>(), hist0,
-                                                                          hist2, hint, h->shift0, h->prm.debug_flags, blocks);
-        }
+        const int lanes = h->prm.lanes_per_point == 4 ? 4 : (h->prm.lanes_per_point == 2 ? 2 : 8);
+        const int blocks = grid_for(h->n * lanes);
+        const dim3 grid(8 * ((blocks + 7) / 8)), block(256);
+        auto go = [&](auto kernel) {
+            launch_timed(h, 0, kernel, grid, block, (const float4*)h->s_xyz.as<float4>(), h->n, it, h->grid,
+                         h->i_pos.as<int>(), h->i_d2.as<float>(), hist0, hist2, hint, h->shift0, h->prm.debug_flags, blocks);
+        };
+        if (lanes == 4)
+            go(k_match_g8<4>);
+        else if (lanes == 2)
+            go(k_match_g8<2>);
+        else
+            go(k_match_g8<8>);
     }
-    prof_mark(h, 0, false);
     h->have_match = true;
     return REG_OK;
 }
@@ -250,12 +264,10 @@ static FilterCfg make_filter_cfg(const reg_handle* h, int trim_mode) {
 template <int G>
 static void launch_fused(reg_handle* h, const FilterCfg& f, float* w, uint8_t* hint) {
     const int blocks = grid_for(h->n * G);
-    prof_mark(h, 1, true);
-    k_iter_fused<G><<<8 * ((blocks + 7) / 8), 256, 0, h->stream>>>(
-        h->s_xyz.as<float4>(), h->has_snrm ? h->s_nrm.as<float4>() : nullptr, h->n, h->i_iter.as<IterState>(), h->grid,
-        h->t_nrm.as<float4>(), f, h->i_pos.as<int>(), h->i_d2.as<float>(), w, hint, h->i_band.as<float>(), kBandCap,
-        h->i_acc.as<double>(), blocks);
-    prof_mark(h, 1, false);
+    launch_timed(h, 1, k_iter_fused<G>, dim3(8 * ((blocks + 7) / 8)), dim3(256), (const float4*)h->s_xyz.as<float4>(),
+                 (const float4*)(h->has_snrm ? h->s_nrm.as<float4>() : nullptr), h->n, h->i_iter.as<IterState>(), h->grid,
+                 (const float4*)h->t_nrm.as<float4>(), f, h->i_pos.as<int>(), h->i_d2.as<float>(), w, hint,
+                 h->i_band.as<float>(), (int)kBandCap, h->i_acc.as<double>(), blocks);
     ++h->seq;
     k_reduce_update<<<1, 1024, 0, h->stream>>>(h->i_acc.as<double>(), blocks, h->i_iter.as<IterState>(), h->d_mirror,
                                                h->seq, 1, h->i_band.as<float>(), w, nullptr, nullptr, 0, 0, nullptr);

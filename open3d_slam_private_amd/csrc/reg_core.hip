@@ -6,6 +6,7 @@
 #include "reg_kernels.hpp"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
