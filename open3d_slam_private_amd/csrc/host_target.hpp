@@ -374,7 +374,6 @@ static reg_status build_grid(reg_handle* h, float c, const float bmin[3], const 
     g.bdx = bdx;
     g.bdy = bdy;
     g.bdz = bdz;
-    g.wide_scan = (h->prm.debug_flags & 16) ? 0 : 1;
     size_t ex_bytes = 0;
     HIPCHK(h, rocprim::exclusive_scan(nullptr, ex_bytes, h->t_cells.as<uint32_t>(), h->t_cells.as<uint32_t>(), 0u,
                                       n_cells, rocprim::plus<uint32_t>(), h->stream));

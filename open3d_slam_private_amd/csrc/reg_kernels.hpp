@@ -56,7 +56,6 @@ struct Grid {
     // small enough to be stored densely (null otherwise).
     const int32_t* brick_dir;
     int bdx, bdy, bdz;
-    int wide_scan;               // 1: levels are scanned with 4 row segments per lane in flight (nearest_group)
 };
 
 struct Xf {  // row-major 3x4
@@ -413,7 +412,7 @@ __device__ __forceinline__ void scan_level_wide(const Grid& g, const float3 p, i
 // 16-byte records, i.e. one or two cache lines per group step instead of one line per lane.
 template <int G>
 __device__ __forceinline__ Best nearest_group(const Grid& g, float3 p, int sub, int first_level, int* level_out,
-                                              uint32_t* seg = nullptr, int after_halo = -1) {
+                                              uint32_t* seg, int after_halo = -1) {
     Best best;
     best.d2 = INFINITY;
     best.idx = 0xffffffffu;
@@ -457,97 +456,13 @@ __device__ __forceinline__ Best nearest_group(const Grid& g, float3 p, int sub, 
     }
     l = max(max(l, after_halo), 0);   // no halo level (or the query lies outside its grid): the hinted level
     for (; l < g.n_levels; ++l) {
-        if (seg && g.wide_scan) {
-            scan_level_wide<G>(g, p, sub, gbase, l, seg, best);
-            best = group_min<G>(best);
-            const float rw = g.rho[l];
-            if (best.pos >= 0 && best.d2 <= rw * rw) break;
-            if (best.pos >= 0) {
-                while (l + 2 < g.n_levels) {
-                    const float rn = g.rho[l + 1];
-                    if (rn * rn >= best.d2) break;
-                    ++l;
-                }
-            }
-            continue;
-        }
-        const float rb = g.rho_box[l];
-        const int lox = (int)fminf(fmaxf(bin_coord_f(p.x - rb, g.ox, g.inv_c), 0.f), g.dimx - 1.f);
-        const int loy = (int)fminf(fmaxf(bin_coord_f(p.y - rb, g.oy, g.inv_c), 0.f), g.dimy - 1.f);
-        const int loz = (int)fminf(fmaxf(bin_coord_f(p.z - rb, g.oz, g.inv_c), 0.f), g.dimz - 1.f);
-        const int hix = (int)fminf(fmaxf(bin_coord_f(p.x + rb, g.ox, g.inv_c), 0.f), g.dimx - 1.f);
-        const int hiy = (int)fminf(fmaxf(bin_coord_f(p.y + rb, g.oy, g.inv_c), 0.f), g.dimy - 1.f);
-        const int hiz = (int)fminf(fmaxf(bin_coord_f(p.z + rb, g.oz, g.inv_c), 0.f), g.dimz - 1.f);
-        const int ny = hiy - loy + 1, nz = hiz - loz + 1;
-        const int bx0 = lox >> kBrickLog2;
-        const int nbx = (hix >> kBrickLog2) - bx0 + 1;
-        const int nrow = nbx * ny;
-        const int total = nrow * nz;
-        for (int base = 0; base < total; base += G) {
-            // phase 1: one segment per lane
-            uint32_t s = 0, e = 0;
-            const int t = base + sub;
-            if (t < total) {
-                const int iz = t / nrow, rem = t - iz * nrow;
-                const int iy = rem / nbx, ix = rem - iy * nbx;
-                const int bx = bx0 + ix, cy = loy + iy, cz = loz + iz;
-                const int bid = brick_lookup(g, bx, cy >> kBrickLog2, cz >> kBrickLog2);
-                if (bid >= 0) {
-                    const int x0 = max(lox, bx << kBrickLog2) & (kBrickDim - 1);
-                    const int x1 = min(hix, (bx << kBrickLog2) + kBrickDim - 1) & (kBrickDim - 1);
-                    const uint32_t* cs = g.cell_start + (size_t)bid * kBrickCells +
-                                         (((cz & (kBrickDim - 1)) << (2 * kBrickLog2)) |
-                                          ((cy & (kBrickDim - 1)) << kBrickLog2));
-                    s = cs[x0];
-                    e = cs[x1 + 1];
-                }
-            }
-            // phase 2: the group scans the CONCATENATION of its (up to 8) segments: flat candidate f belongs
-            // to the segment k with ex[k] <= f < ex[k+1]; lane `sub` takes f = sub, sub+8, ... and keeps
-            // kUnroll independent 16-byte loads in flight (the kernel is latency-bound, not bandwidth-bound).
-            const uint32_t cnt = e - s;
-            uint32_t incl = cnt;
-#pragma unroll
-            for (int o = 1; o < G; o <<= 1) {
-                const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
-                if (sub >= o) incl += v;
-            }
-            const uint32_t total_pts = (uint32_t)__shfl((int)incl, gbase + G - 1);
-            if (total_pts == 0) continue;
-            uint32_t ex[G], st[G];
-#pragma unroll
-            for (int k = 0; k < G; ++k) {
-                ex[k] = (uint32_t)__shfl((int)(incl - cnt), gbase + k);
-                st[k] = (uint32_t)__shfl((int)s, gbase + k);
-            }
-            constexpr int kUnroll = 4;
-            for (uint32_t f0 = 0; f0 < total_pts; f0 += kUnroll * G) {
-                float4 tv[kUnroll];
-                uint32_t jv[kUnroll];
-#pragma unroll
-                for (int u = 0; u < kUnroll; ++u) {
-                    const uint32_t f = min(f0 + (uint32_t)(u * G + sub), total_pts - 1);  // clamp: duplicates are harmless
-                    uint32_t base_pt = st[0], base_f = 0;
-#pragma unroll
-                    for (int k = 1; k < G; ++k)
-                        if (f >= ex[k]) {
-                            base_pt = st[k];
-                            base_f = ex[k];
-                        }
-                    jv[u] = base_pt + (f - base_f);
-                    tv[u] = g.pts[jv[u]];
-                }
-#pragma unroll
-                for (int u = 0; u < kUnroll; ++u) consider(g, p, tv[u], (int)jv[u], best);
-            }
-        }
+        scan_level_wide<G>(g, p, sub, gbase, l, seg, best);
         best = group_min<G>(best);
-        const float r = g.rho[l];
-        const float r2 = r * r;
-        if (best.pos >= 0 && best.d2 <= r2) break;  // every point within rho was inside the box: exact
+        const float rw = g.rho[l];
+        if (best.pos >= 0 && best.d2 <= rw * rw) break;   // every point within rho was inside the box: exact
         if (best.pos >= 0) {
-            // a candidate at distance sqrt(best.d2) exists, so the true neighbour is no farther: jump straight to
-            // the first radius that covers it (the levels in between could not terminate either)
+            // a candidate at distance sqrt(best.d2) exists, so the true neighbour is no farther: jump straight to the
+            // first radius that covers it (the levels in between could not terminate either)
             while (l + 2 < g.n_levels) {
                 const float rn = g.rho[l + 1];
                 if (rn * rn >= best.d2) break;
