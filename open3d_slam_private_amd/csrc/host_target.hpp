@@ -60,7 +60,7 @@ struct reg_handle {
     bool device_ok = false;   // false: reg_create could not get a HIP device (every entry point then fails loudly)
     bool structure_only = false;   // workspace handle of reg_estimate_normals: bin table only, no attributes
     reg_handle* normals_ws = nullptr;
-    DevBuf n_out, n_eig, n_cov, n_ids, n_extra;
+    DevBuf n_out, n_eig, n_cov, n_ids, n_extra, n_mom;
     DevBuf i_xicp;                 // XicpState (R8x first-iteration analysis)
     DevBuf c_in_xyz, c_in_nrm, c_in_cov, c_flags, c_offs, c_xyz, c_nrm, c_cov, c_idx;   // reg_set_target_f64
     int64_t crop_kept = 0;
@@ -230,6 +230,7 @@ void reg_destroy(reg_handle* h) {
     h->n_cov.release();
     h->n_ids.release();
     h->n_extra.release();
+    h->n_mom.release();
     DevBuf* bufs[] = {&h->t_raw, &h->t_nrm_raw, &h->t_cov_raw, &h->t_centred, &h->t_keys, &h->t_keys2, &h->t_vals,
                       &h->t_vals2, &h->t_pts, &h->t_nrm, &h->t_cov, &h->t_flags, &h->t_scan, &h->t_hash, &h->t_cells,
                       &h->t_tmp, &h->t_misc, &h->t_dir, &h->s_raw, &h->s_nrm_raw, &h->s_cov_raw, &h->s_xyz, &h->s_nrm, &h->s_cov,
@@ -1041,8 +1042,11 @@ reg_status reg_estimate_normals(reg_handle* h, const float* xyz, int64_t xyz_str
     HIPCHK(h, hipMemsetAsync(w->t_misc.p, 0, 4, h->stream));
     const float vp[3] = {viewpoint ? viewpoint[0] : 0.f, viewpoint ? viewpoint[1] : 0.f, viewpoint ? viewpoint[2] : 0.f};
     const int64_t blocks = (n + (256 / kPcaGroup) - 1) / (256 / kPcaGroup);
-    k_knn_pca<<<(unsigned)blocks, 256, 0, h->stream>>>(w->grid, d_raw, xyz_stride, n, k, start, vp[0], vp[1], vp[2], viewpoint ? 1 : 0,
-                                                       regularise, d_n, d_e, d_c, d_i, w->t_misc.as<uint32_t>(), d_v, d_d, d_m);
+    HIPCHK(h, h->n_mom.reserve((size_t)n * sizeof(PcaMoments)));
+    k_knn_pca<<<(unsigned)blocks, 256, 0, h->stream>>>(w->grid, d_raw, xyz_stride, n, k, start, d_i, w->t_misc.as<uint32_t>(),
+                                                       h->n_mom.as<PcaMoments>());
+    k_pca_finish<<<grid_for(n), 256, 0, h->stream>>>(h->n_mom.as<PcaMoments>(), n, vp[0], vp[1], vp[2], viewpoint ? 1 : 0,
+                                                     regularise, d_n, d_e, d_c, d_v, d_d, d_m);
     uint32_t resc = 0;
     HIPCHK(h, hipMemcpyAsync(&resc, w->t_misc.p, 4, hipMemcpyDeviceToHost, h->stream));
     if (!on_device) {

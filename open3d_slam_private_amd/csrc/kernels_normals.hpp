@@ -69,11 +69,22 @@ __device__ __forceinline__ void pca_scan_box(const Grid& g, const float3 p, int 
     }
 }
 
+// Per-point result of the neighbourhood kernel, consumed by k_pca_finish (one thread per point: the eigen-decomposition
+// ran on ONE lane of a 16-lane group before -- 6 % lane utilisation for the most expensive arithmetic of the kernel).
+struct PcaMoments {
+    float mean[3];
+    float C[6];      // xx xy xz yy yz zz of sum (q - mean)(q - mean)^T
+    float m;         // neighbours found
+    float p[3];      // the point itself
+    float max_d2;    // largest squared distance of a neighbour from the mean (densities)
+    uint32_t idx;    // original index
+    uint32_t pad;
+};
+static_assert(sizeof(PcaMoments) == 64, "one 64-byte record per point");
+
 __global__ void __launch_bounds__(256)
-k_knn_pca(Grid g, const float* __restrict__ raw_xyz, int64_t raw_stride, int64_t n, int k, int start_level, float vx,
-          float vy, float vz, int has_vp, int regularise, float* __restrict__ normals, float* __restrict__ eigvals,
-          float* __restrict__ covs, int32_t* __restrict__ ids_out, uint32_t* __restrict__ n_overflow,
-          float* __restrict__ eigvecs, float* __restrict__ densities, float* __restrict__ mean_dists) {
+k_knn_pca(Grid g, const float* __restrict__ raw_xyz, int64_t raw_stride, int64_t n, int k, int start_level,
+          int32_t* __restrict__ ids_out, uint32_t* __restrict__ n_overflow, PcaMoments* __restrict__ mom) {
     constexpr int GP = 256 / kPcaGroup;   // points per workgroup
     __shared__ float l_d2[GP][kPcaCap];
     __shared__ uint32_t l_idx[GP][kPcaCap];
@@ -193,6 +204,40 @@ k_knn_pca(Grid g, const float* __restrict__ raw_xyz, int64_t raw_stride, int64_t
         u = dy * dz; C[4] = C[4] + u;
         u = dz * dz; C[5] = C[5] + u;
     }
+    float mx = 0.f;
+    for (int r = 0; r < m; ++r) {
+        const float dx = nb_xyz[grp][r][0] - mean[0], dy = nb_xyz[grp][r][1] - mean[1], dz = nb_xyz[grp][r][2] - mean[2];
+        float u = dx * dx;
+        float v2 = dy * dy;
+        float s2 = u + v2;
+        u = dz * dz;
+        s2 = s2 + u;
+        mx = fmaxf(mx, s2);
+    }
+    PcaMoments rec;
+    rec.mean[0] = mean[0]; rec.mean[1] = mean[1]; rec.mean[2] = mean[2];
+    for (int a = 0; a < 6; ++a) rec.C[a] = C[a];
+    rec.m = fm;
+    rec.p[0] = p.x; rec.p[1] = p.y; rec.p[2] = p.z;
+    rec.max_d2 = mx;
+    rec.idx = my_idx;
+    rec.pad = 0;
+    mom[q] = rec;
+}
+
+// One thread per point: eigen-decomposition of the scatter matrix and every output of the filter.
+__global__ void __launch_bounds__(256)
+k_pca_finish(const PcaMoments* __restrict__ mom, int64_t n, float vx, float vy, float vz, int has_vp, int regularise,
+             float* __restrict__ normals, float* __restrict__ eigvals, float* __restrict__ covs,
+             float* __restrict__ eigvecs, float* __restrict__ densities, float* __restrict__ mean_dists) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const PcaMoments rec = mom[i];
+    const float* mean = rec.mean;
+    const float* C = rec.C;
+    const int m = (int)rec.m;
+    const float3 p = make_float3(rec.p[0], rec.p[1], rec.p[2]);
+    const uint32_t my_idx = rec.idx;
     double M[9] = {C[0], C[1], C[2], C[1], C[3], C[4], C[2], C[4], C[5]}, V[9], lam[3];
     jacobi_eig_sym3(M, V, lam);
     int o0 = 0, o1 = 1, o2 = 2;
@@ -239,16 +284,7 @@ k_knn_pca(Grid g, const float* __restrict__ raw_xyz, int64_t raw_stride, int64_t
     if (densities) {   // utils.h:106-128: m / (4/3 pi r^3), r^2 = largest squared distance of a neighbour from the mean
         float dens = 0.f;
         if (!degenerate) {
-            float mx = 0.f;
-            for (int r = 0; r < m; ++r) {
-                const float dx = nb_xyz[grp][r][0] - mean[0], dy = nb_xyz[grp][r][1] - mean[1], dz = nb_xyz[grp][r][2] - mean[2];
-                float u = dx * dx;
-                float v2 = dy * dy;
-                float s2 = u + v2;
-                u = dz * dz;
-                s2 = s2 + u;
-                mx = fmaxf(mx, s2);
-            }
+            const float mx = rec.max_d2;
             const float tq = (float)(4. / 3.), pi = (float)3.14159265358979323846;
             const float c0 = tq * pi;
             const float r3 = mx * sqrtf(mx);
