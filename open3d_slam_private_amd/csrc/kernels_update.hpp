@@ -349,6 +349,29 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
 #pragma unroll
     for (int i = 0; i < 6; ++i) xsol[i] = __shfl(a, i * 8 + 6);
     st2 = __builtin_amdgcn_s_memtime();
+    // R8x, first iteration: eigen-directions of the rotation (lane 0) and translation (lane 1) blocks of A, expressed in
+    // the frame the data came from (two fp64 Jacobi iterations side by side instead of one after the other on lane 0);
+    // the analysis kernels that follow collect the information sums, then this kernel runs again (finish) to decide,
+    // solve and update.  Nothing is reported to the host yet.
+    const bool stage_a = !finish && sit->update != 0 && p2pl && sit->xicp_stage == 1 && tot[28] != 0.0 && xs != nullptr;
+    if (stage_a && lane < 2) {
+        const int o = lane == 0 ? 0 : 3;   // block offset inside the 6x6 system
+        double S[9], V[9];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                const int lo = (i < j ? i : j) + o, hi = (i < j ? j : i) + o;
+                S[3 * i + j] = (double)(float)tot[lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo)];
+            }
+        eig3_desc(S, V);
+        float* dst = lane == 0 ? xs->vr : xs->vt;
+        for (int kk = 0; kk < 3; ++kk)
+            for (int rr = 0; rr < 3; ++rr) {
+                const float a0 = sit->xicp_Trd[rr] * (float)V[kk], a1 = sit->xicp_Trd[4 + rr] * (float)V[3 + kk];
+                const float a2 = sit->xicp_Trd[8 + rr] * (float)V[6 + kk];
+                const float sacc = a0 + a1;
+                dst[3 * kk + rr] = sacc + a2;
+            }
+    }
     if (lane == 0) {
         // band for the next iteration from the limits seen so far
         const float limit = finish ? sit->limit_last : s_limit;
@@ -373,32 +396,7 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
         sit->band_count = 0;
         sit->stall = 0;
         bool do_update = sit->update != 0;
-        if (!finish && do_update && p2pl && sit->xicp_stage == 1 && tot[28] != 0.0 && xs) {
-            // R8x, first iteration: eigen-directions of the rotation / translation blocks of A, expressed in the frame
-            // the data came from; the analysis kernels that follow collect the information sums, then this kernel
-            // runs again (finish) to decide, solve and update.  Nothing is reported to the host yet.
-            float H[36];
-            int k = 0;
-            for (int i = 0; i < 6; ++i)
-                for (int j = i; j < 6; ++j) {
-                    const float v = (float)tot[k++];
-                    H[6 * i + j] = v;
-                    H[6 * j + i] = v;
-                }
-            double Vr[9], Vt[9];
-            xicp_eigvecs(H, Vr, Vt);
-            for (int kk = 0; kk < 3; ++kk)
-                for (int rr = 0; rr < 3; ++rr) {
-                    float a0 = sit->xicp_Trd[rr] * (float)Vr[kk], a1 = sit->xicp_Trd[4 + rr] * (float)Vr[3 + kk];
-                    float a2 = sit->xicp_Trd[8 + rr] * (float)Vr[6 + kk];
-                    float sacc = a0 + a1;
-                    xs->vr[3 * kk + rr] = sacc + a2;
-                    a0 = sit->xicp_Trd[rr] * (float)Vt[kk];
-                    a1 = sit->xicp_Trd[4 + rr] * (float)Vt[3 + kk];
-                    a2 = sit->xicp_Trd[8 + rr] * (float)Vt[6 + kk];
-                    sacc = a0 + a1;
-                    xs->vt[3 * kk + rr] = sacc + a2;
-                }
+        if (stage_a) {
             for (int i = 0; i < 4; ++i) xs->center[i] = 0.0;
             for (int i = 0; i < 6; ++i) {
                 xs->comb[i] = 0.0;
