@@ -1043,8 +1043,12 @@ reg_status reg_estimate_normals(reg_handle* h, const float* xyz, int64_t xyz_str
     const float vp[3] = {viewpoint ? viewpoint[0] : 0.f, viewpoint ? viewpoint[1] : 0.f, viewpoint ? viewpoint[2] : 0.f};
     const int64_t blocks = (n + (256 / kPcaGroup) - 1) / (256 / kPcaGroup);
     HIPCHK(h, h->n_mom.reserve((size_t)n * sizeof(PcaMoments)));
-    k_knn_pca<<<(unsigned)blocks, 256, 0, h->stream>>>(w->grid, d_raw, xyz_stride, n, k, start, d_i, w->t_misc.as<uint32_t>(),
-                                                       h->n_mom.as<PcaMoments>());
+    if (k <= 12)
+        k_knn_pca<128><<<(unsigned)blocks, 256, 0, h->stream>>>(w->grid, d_raw, xyz_stride, n, k, start, d_i,
+                                                                w->t_misc.as<uint32_t>(), h->n_mom.as<PcaMoments>());
+    else
+        k_knn_pca<256><<<(unsigned)blocks, 256, 0, h->stream>>>(w->grid, d_raw, xyz_stride, n, k, start, d_i,
+                                                                w->t_misc.as<uint32_t>(), h->n_mom.as<PcaMoments>());
     k_pca_finish<<<grid_for(n), 256, 0, h->stream>>>(h->n_mom.as<PcaMoments>(), n, vp[0], vp[1], vp[2], viewpoint ? 1 : 0,
                                                      regularise, d_n, d_e, d_c, d_v, d_d, d_m);
     uint32_t resc = 0;

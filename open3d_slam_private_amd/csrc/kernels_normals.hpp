@@ -12,7 +12,8 @@
 // list held every closer point (same exactness argument as the 1-NN search).
 // =================================================================================================
 constexpr int kPcaGroup = 16;
-constexpr int kPcaCap = 256;     // candidates per point and level held in LDS (8 B each)
+// candidates per point and level held in LDS (8 B each): a template parameter of the kernel -- 128 (25 KB per workgroup,
+// 6 workgroups per CU) is enough for small k, 256 (41 KB, 3 per CU) keeps the rescans rare for k up to 32
 constexpr int kPcaMaxK = 32;
 
 // Calls f(j, target point j, d2) on the lanes of one 16-lane group for every target point inside the bin box of
@@ -82,6 +83,7 @@ struct PcaMoments {
 };
 static_assert(sizeof(PcaMoments) == 64, "one 64-byte record per point");
 
+template <int kPcaCap>
 __global__ void __launch_bounds__(256)
 k_knn_pca(Grid g, const float* __restrict__ raw_xyz, int64_t raw_stride, int64_t n, int k, int start_level,
           int32_t* __restrict__ ids_out, uint32_t* __restrict__ n_overflow, PcaMoments* __restrict__ mom) {
