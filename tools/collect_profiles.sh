@@ -10,6 +10,7 @@ CMD="python bench.py --steps 10 --warmup 2 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/bench_trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $CMD > $OUT/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $CMD > $OUT/bench_write.log 2>&1
+[ -x tools/tools_calib ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o tools/tools_calib tools/tools_calib.hip
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/calib_fetch -- ./tools/tools_calib > $OUT/calib.log 2>&1
 # next-row kernel (normals / covariances): kernel trace + stats of 1 M points, k = 10
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/normals -- python tools/tools_normals.py 1000000 10 > $OUT/normals.log 2>&1
