@@ -108,13 +108,19 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
     if (n_band) {
 #pragma unroll
         for (int u = 0; u < kBandCap / 1024; ++u) {
-            const uint32_t i = threadIdx.x + 1024u * u;
-            my_d2[u] = i < n_band ? __float_as_uint(rec(i, 29)) : 0u;
+            my_d2[u] = 0u;
+            if (1024u * u < n_band) {   // workgroup-uniform: a band of a few hundred records issues one load, not 16
+                const uint32_t i = threadIdx.x + 1024u * u;
+                if (i < n_band) my_d2[u] = __float_as_uint(rec(i, 29));
+            }
         }
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
-            const uint32_t i = min((uint32_t)part + 32u * u, n_band - 1);
-            pre[u] = add_comp ? rec(i, comp) : 0.f;
+            pre[u] = 0.f;
+            if (32u * u < n_band) {     // workgroup-uniform
+                const uint32_t i = min((uint32_t)part + 32u * u, n_band - 1);
+                if (add_comp) pre[u] = rec(i, comp);
+            }
         }
     }
     if (gathered) {
@@ -171,7 +177,7 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
 #pragma unroll
             for (int u = 0; u < kBandCap / 1024; ++u) {
                 const uint32_t i = threadIdx.x + 1024u * u;
-                if (i < n_band) bd2[i] = my_d2[u];
+                if (1024u * u < n_band && i < n_band) bd2[i] = my_d2[u];
             }
             // One-level select: the band's values lie in [band_lo, band_hi), so the order-preserving key
             // (u - u_lo) * 2048 / (u_hi - u_lo) spreads them over 2048 bins (about one value per bin); the bin that
@@ -269,7 +275,7 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
                     const uint32_t i = (uint32_t)part + 32u * u;
-                    if (i < n_band && __uint_as_float(bd2[i]) <= limit) acc += (double)pre[u];
+                    if (32u * u < n_band && i < n_band && __uint_as_float(bd2[i]) <= limit) acc += (double)pre[u];
                 }
                 for (uint32_t i0 = part + 32u * 16u; i0 < n_band; i0 += 32 * 16) {   // only when n_band > 512
                     float vv[16];
