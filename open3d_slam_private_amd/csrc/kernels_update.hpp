@@ -65,6 +65,23 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
         const int n_rows = fused ? kAccRows : n_blocks;
         for (int b = part; b < n_rows; b += 32) t += partials[(size_t)b * kSums + comp];
     }
+    // Single-GPU fused path: the first kSpec * 32 band records (the usual band holds fewer) are loaded speculatively in
+    // the same batch as the state -- their addresses do not depend on the record count, only their validity does; this
+    // takes one dependent round trip (state -> band) off the kernel's critical path.  Slots beyond the count hold stale
+    // records of earlier iterations and are masked at every use.
+    constexpr int kSpec = 6;
+    const bool spec = fused == 1 && !gathered && band != nullptr;
+    uint32_t spec_d2 = 0;
+    float spec_pre[kSpec];
+#pragma unroll
+    for (int u = 0; u < kSpec; ++u) spec_pre[u] = 0.f;
+    if (spec) {
+        spec_d2 = __float_as_uint(band[band_at(29, threadIdx.x)]);
+        if (comp != 29 && comp != 31) {
+#pragma unroll
+            for (int u = 0; u < kSpec; ++u) spec_pre[u] = band[band_at(comp, (uint32_t)part + 32u * u)];
+        }
+    }
     __syncthreads();
     const int s_done = sit->done, s_stall = sit->stall, s_use_trim = sit->use_trim;
     const float s_ratio = sit->trim_ratio, s_band_lo = sit->band_lo, s_band_hi = sit->band_hi;
@@ -109,7 +126,9 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
 #pragma unroll
         for (int u = 0; u < kBandCap / 1024; ++u) {
             my_d2[u] = 0u;
-            if (1024u * u < n_band) {   // workgroup-uniform: a band of a few hundred records issues one load, not 16
+            if (u == 0 && spec) {
+                my_d2[0] = spec_d2;
+            } else if (1024u * u < n_band) {   // workgroup-uniform: a band of a few hundred records issues one load, not 16
                 const uint32_t i = threadIdx.x + 1024u * u;
                 if (i < n_band) my_d2[u] = __float_as_uint(rec(i, 29));
             }
@@ -117,7 +136,9 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             pre[u] = 0.f;
-            if (32u * u < n_band) {     // workgroup-uniform
+            if (u < kSpec && spec) {
+                pre[u] = spec_pre[u < kSpec ? u : 0];
+            } else if (32u * u < n_band) {     // workgroup-uniform
                 const uint32_t i = min((uint32_t)part + 32u * u, n_band - 1);
                 if (add_comp) pre[u] = rec(i, comp);
             }
