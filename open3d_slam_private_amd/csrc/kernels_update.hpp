@@ -29,6 +29,62 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_s_barrier();
 }
 
+// Rare, register-hungry branches of the update kernel's serial section, kept out of line: inlined, their fully
+// unrolled fp64 eigen-solves pushed the kernel (capped at 128 VGPRs by its 1024-thread workgroup) to ~700 spilled
+// registers, and the spill traffic landed on the common path as scratch round trips.  Results go through LDS so
+// that the caller's arrays stay in registers.
+__device__ __noinline__ void upd_load_sym6(const double* tot, float* H, float* b6) {
+    int k = 0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 6; ++j) {
+            const float v = (float)tot[k++];
+            H[6 * i + j] = v;
+            H[6 * j + i] = v;
+        }
+    for (int i = 0; i < 6; ++i) b6[i] = -(float)tot[21 + i];
+}
+__device__ __noinline__ int upd_solve6_xicp(const double* tot, const int* flags, float* x_out) {
+    float H[36], b6[6], x[6];
+    upd_load_sym6(tot, H, b6);
+    const int rank = solve6_xicp(H, b6, flags, x);
+    for (int i = 0; i < 6; ++i) x_out[i] = x[i];
+    return rank;
+}
+__device__ __noinline__ int upd_solve6_p2pl(const double* tot, float* x_out) {
+    float H[36], b6[6], x[6];
+    upd_load_sym6(tot, H, b6);
+    const int rank = solve6_p2pl(H, b6, x);
+    for (int i = 0; i < 6; ++i) x_out[i] = x[i];
+    return rank;
+}
+__device__ __noinline__ int upd_solve_sym6(const double* tot, double* dl_out) {
+    double Hd[36], g[6], dl[6];
+    int k = 0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 6; ++j) Hd[6 * i + j] = Hd[6 * j + i] = tot[k++];
+    for (int i = 0; i < 6; ++i) g[i] = -tot[21 + i];
+    const int rank = solve_sym6(Hd, g, dl, 1e-12);
+    for (int i = 0; i < 6; ++i) dl_out[i] = dl[i];
+    return rank;
+}
+// R8x stage A for one 3x3 block (o = 0: rotation, 3: translation) of the system
+__device__ __noinline__ void upd_xicp_stage_a(const double* tot, const float* Trd, float* dst, int o) {
+    double S[9], V[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            const int lo = (i < j ? i : j) + o, hi = (i < j ? j : i) + o;
+            S[3 * i + j] = (double)(float)tot[lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo)];
+        }
+    eig3_desc(S, V);
+    for (int kk = 0; kk < 3; ++kk)
+        for (int rr = 0; rr < 3; ++rr) {
+            const float a0 = Trd[rr] * (float)V[kk], a1 = Trd[4 + rr] * (float)V[3 + kk];
+            const float a2 = Trd[8 + rr] * (float)V[6 + kk];
+            const float sacc = a0 + a1;
+            dst[3 * kk + rr] = sacc + a2;
+        }
+}
+
 __global__ void __launch_bounds__(1024)
 k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it, HostMirror* host,
                 unsigned long long seq, int fused, const float* __restrict__ band, float* __restrict__ w_out,
@@ -51,6 +107,8 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
     __shared__ uint32_t rk_off[65];   // multi-GPU: first global band index of every rank's records (+ total)
     __shared__ uint32_t rk_bad;
     __shared__ int s_skip_mirror;
+    __shared__ float s_x[6];     // results of the out-of-line solvers (rare branches of the serial section)
+    __shared__ double s_dl[6];
     // The whole iteration state is staged in LDS by one coalesced load (every separate `it->` access below would
     // cost an L2 round trip on a single lane); wave 0 writes the modified copy back at the end.  The accumulator
     // rows do not depend on the state, so their loads are issued in the same batch.
@@ -344,6 +402,18 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
     const unsigned long long st1 = __builtin_amdgcn_s_memtime();
     unsigned long long st2 = st1, st3 = st1;
     const bool p2pl = sit->cost == REG_COST_P2PL;
+    // Everything lane 0 will read from the LDS-resident state is fetched here in one batch, behind the solve below: read
+    // one by one inside the serial section, every access cost its own ~100-cycle LDS round trip (3.4 k cycles measured
+    // before the pose update even started).
+    const float r_limit_last = sit->limit_last, r_limit_sel = s_limit;
+    const int r_dbg_narrow = sit->debug_narrow_band, r_update = sit->update, r_xstage = sit->xicp_stage;
+    const int r_fixed = sit->fixed_iters, r_iters = sit->iterations;
+    int r_xnc = sit->xicp_nc;
+    const unsigned r_band_count = sit->band_count;
+    const double r_tot28 = tot[28];
+    float r_T[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r_T[i] = sit->T[i];
     // ---- R8: 6x6 solve by Gauss-Jordan elimination on the augmented 6x7 system, one entry per lane (fp64).
     // P2PL: A, b are first rounded to fp32 (the reference hands fp32 matrices to its fp64 solver).
     const int r = lane >> 3, c = lane & 7;
@@ -380,30 +450,13 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
     // the frame the data came from (two fp64 Jacobi iterations side by side instead of one after the other on lane 0);
     // the analysis kernels that follow collect the information sums, then this kernel runs again (finish) to decide,
     // solve and update.  Nothing is reported to the host yet.
-    const bool stage_a = !finish && sit->update != 0 && p2pl && sit->xicp_stage == 1 && tot[28] != 0.0 && xs != nullptr;
-    if (stage_a && lane < 2) {
-        const int o = lane == 0 ? 0 : 3;   // block offset inside the 6x6 system
-        double S[9], V[9];
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) {
-                const int lo = (i < j ? i : j) + o, hi = (i < j ? j : i) + o;
-                S[3 * i + j] = (double)(float)tot[lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo)];
-            }
-        eig3_desc(S, V);
-        float* dst = lane == 0 ? xs->vr : xs->vt;
-        for (int kk = 0; kk < 3; ++kk)
-            for (int rr = 0; rr < 3; ++rr) {
-                const float a0 = sit->xicp_Trd[rr] * (float)V[kk], a1 = sit->xicp_Trd[4 + rr] * (float)V[3 + kk];
-                const float a2 = sit->xicp_Trd[8 + rr] * (float)V[6 + kk];
-                const float sacc = a0 + a1;
-                dst[3 * kk + rr] = sacc + a2;
-            }
-    }
+    const bool stage_a = !finish && r_update != 0 && p2pl && r_xstage == 1 && r_tot28 != 0.0 && xs != nullptr;
+    if (stage_a && lane < 2) upd_xicp_stage_a(tot, sit->xicp_Trd, lane == 0 ? xs->vr : xs->vt, lane == 0 ? 0 : 3);
     if (lane == 0) {
         // band for the next iteration from the limits seen so far
-        const float limit = finish ? sit->limit_last : s_limit;
+        const float limit = finish ? r_limit_last : r_limit_sel;
         if (!finish) {
-            sit->limit_prev = sit->limit_last;
+            sit->limit_prev = r_limit_last;
             sit->limit_last = limit;
         }
         if (finish) {
@@ -412,17 +465,17 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
             sit->band_lo = INFINITY;   // no trimming / nothing to predict from: every finite match is "certainly kept"
             sit->band_hi = INFINITY;
         } else {
-            const float prev = sit->limit_prev;
+            const float prev = r_limit_last;   // == the new limit_prev
             float m = 0.3f;
             if (prev < INFINITY && prev > 0.f) m = fminf(fmaxf(2.0f * fabsf(limit - prev) / limit + 0.003f, 0.003f), 0.6f);
-            if (sit->debug_narrow_band) m = 1e-7f;   // test hook: forces band mispredictions (stall + repair path)
+            if (r_dbg_narrow) m = 1e-7f;   // test hook: forces band mispredictions (stall + repair path)
             sit->band_lo = limit * (1.0f - m);
             sit->band_hi = limit * (1.0f + m);
         }
-        const int nband_report = (int)sit->band_count;
+        const int nband_report = (int)r_band_count;
         sit->band_count = 0;
         sit->stall = 0;
-        bool do_update = sit->update != 0;
+        bool do_update = r_update != 0;
         if (stage_a) {
             for (int i = 0; i < 4; ++i) xs->center[i] = 0.0;
             for (int i = 0; i < 6; ++i) {
@@ -443,50 +496,35 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
                 nc += ok ? 0 : 1;
             }
             sit->xicp_nc = nc;
+            r_xnc = nc;
             sit->xicp_stage = 0;
         }
         if (do_update) {
-            if (tot[28] == 0.0) {
+            if (r_tot28 == 0.0) {
                 sit->status = REG_NO_CORRESPONDENCES;
                 sit->done = 1;
             } else if (p2pl) {
                 float x[6], dT[16], Tn[16];
                 int rank = 6;
-                if (sit->xicp_nc > 0) {
+                if (r_xnc > 0) {
                     // R8x: no update along the non-localizable eigen-directions of the CURRENT A (PointToPlane.cpp:459-505)
-                    float H[36], b6[6];
-                    int k = 0;
-                    for (int i = 0; i < 6; ++i)
-                        for (int j = i; j < 6; ++j) {
-                            const float v = (float)tot[k++];
-                            H[6 * i + j] = v;
-                            H[6 * j + i] = v;
-                        }
-                    for (int i = 0; i < 6; ++i) b6[i] = -(float)tot[21 + i];
-                    rank = solve6_xicp(H, b6, sit->xicp_flags, x);
+                    rank = upd_solve6_xicp(tot, sit->xicp_flags, s_x);
+                    for (int i = 0; i < 6; ++i) x[i] = s_x[i];
                 } else if (well) {
                     for (int i = 0; i < 6; ++i) x[i] = (float)xsol[i];
                 } else {
                     // ill-conditioned / rank deficient: eigen-solve with the fp32 rank threshold (minimum norm)
-                    float H[36], b6[6];
-                    int k = 0;
-                    for (int i = 0; i < 6; ++i)
-                        for (int j = i; j < 6; ++j) {
-                            const float v = (float)tot[k++];
-                            H[6 * i + j] = v;
-                            H[6 * j + i] = v;
-                        }
-                    for (int i = 0; i < 6; ++i) b6[i] = -(float)tot[21 + i];
-                    rank = solve6_p2pl(H, b6, x);
+                    rank = upd_solve6_p2pl(tot, s_x);
+                    for (int i = 0; i < 6; ++i) x[i] = s_x[i];
                 }
                 sit->rank_last = rank;
                 x_to_T(x, dT);
-                m4_mul(dT, sit->T, Tn);  // T_iter = real * T_iter (ICP.cpp:1213-1215)
+                m4_mul(dT, r_T, Tn);  // T_iter = real * T_iter (ICP.cpp:1213-1215)
                 for (int i = 0; i < 16; ++i) sit->T[i] = Tn[i];
-                sit->iterations += 1;
+                sit->iterations = r_iters + 1;
                 bool iterate;
-                if (sit->fixed_iters > 0)
-                    iterate = sit->iterations < sit->fixed_iters;
+                if (r_fixed > 0)
+                    iterate = r_iters + 1 < r_fixed;
                 else
                     iterate = sit->chk.check(Tn);
                 if (!iterate) sit->done = 1;
@@ -496,12 +534,8 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
                 if (well) {
                     for (int i = 0; i < 6; ++i) dl[i] = xsol[i];
                 } else {
-                    double Hd[36], g[6];
-                    int k = 0;
-                    for (int i = 0; i < 6; ++i)
-                        for (int j = i; j < 6; ++j) Hd[6 * i + j] = Hd[6 * j + i] = tot[k++];
-                    for (int i = 0; i < 6; ++i) g[i] = -tot[21 + i];
-                    rank = solve_sym6(Hd, g, dl, 1e-12);
+                    rank = upd_solve_sym6(tot, s_dl);
+                    for (int i = 0; i < 6; ++i) dl[i] = s_dl[i];
                 }
                 sit->rank_last = rank;
                 se3_exp(dl, E);
