@@ -57,6 +57,36 @@ __device__ __forceinline__ void p2pl_products(float3 p, float4 q, float4 nn, flo
     vals[27] = w * rr;
 }
 
+// Component k of the 32 sums as a product E[a_k] * E[c_k] of two entries of the per-point factor table
+// E = {F0..F5, r, 1}: k < 21 upper triangle F_a F_c (a <= c), 21..26 F_a r, 27 r r; 28..31 are counts (set directly).
+// Entries are BYTE offsets into E.  One lane of a group publishes E in LDS; every lane forms only its own components.
+struct alignas(16) ProdCode {
+    uint8_t a[32];
+    uint8_t c[32];
+};
+constexpr ProdCode make_prod_code() {
+    ProdCode t{};
+    int k = 0;
+    for (int a6 = 0; a6 < 6; ++a6)
+        for (int c6 = a6; c6 < 6; ++c6) {
+            t.a[k] = (uint8_t)(4 * a6);
+            t.c[k] = (uint8_t)(4 * c6);
+            ++k;
+        }
+    for (int a6 = 0; a6 < 6; ++a6) {
+        t.a[21 + a6] = (uint8_t)(4 * a6);
+        t.c[21 + a6] = 4 * 6;
+    }
+    t.a[27] = 4 * 6;
+    t.c[27] = 4 * 6;
+    for (int s = 28; s < 32; ++s) {
+        t.a[s] = 4 * 7;
+        t.c[s] = 4 * 7;
+    }
+    return t;
+}
+__device__ const ProdCode kProdCode = make_prod_code();
+
 template <int G>
 __global__ void __launch_bounds__(256, O3D_MATCH_WAVES)
 k_iter_fused(const float4* __restrict__ src, const float4* __restrict__ src_nrm, int64_t n, IterState* __restrict__ it,
@@ -64,36 +94,57 @@ k_iter_fused(const float4* __restrict__ src, const float4* __restrict__ src_nrm,
              float* __restrict__ d2_out, float* __restrict__ w_out, uint8_t* __restrict__ hint,
              float* __restrict__ band, int band_cap, double* __restrict__ partials, int n_blocks) {
     constexpr int CP = kSums / G;   // components owned by each lane of a group
+    static_assert(CP % 4 == 0 && CP >= 4, "a lane owns whole code words (4 components each)");
     __shared__ double sh[4][kSums];
     __shared__ uint32_t seg_lds[(256 / G) * kSegWords<G>];
-    if (it->done || it->stall) return;
-    const Xf T = load_xf(it);
-    const float band_lo = it->band_lo, band_hi = it->band_hi;
     const int lb = xcd_block(n_blocks);
     const int64_t tid = lb * (int64_t)blockDim.x + threadIdx.x;
     const int64_t q = lb < n_blocks ? (tid / G) : n;
     const int sub = (int)(tid & (G - 1));
+    // What does not depend on the iteration state is requested BEFORE the state is looked at: the reading point and
+    // its hint travel together with the state's scalar loads (the kernel is bound by its chain of dependent round
+    // trips, not by instruction issue: see DESIGN.md).  Unconditional loads from clamped addresses: a load under a
+    // branch makes the compiler wait for it at the join.
+    const int64_t qc = q < n ? q : n - 1;
+    const float4 s = src[qc];
+    const uint8_t hraw = *(hint ? hint + qc : reinterpret_cast<const uint8_t*>(src));
+    const int hv = hint ? (int)hraw : 0;
+    // one batch of scalar loads for every state field (tested one after the other they cost a round trip each; the
+    // empty asm keeps the compiler from sinking the pose loads below the early exit)
+    const int st_done = it->done, st_stall = it->stall;
+    const Xf T = load_xf(it);
+    const float band_lo = it->band_lo, band_hi = it->band_hi;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) asm volatile("" ::"s"(T.m[k]));
+    asm volatile("" ::"s"(band_lo), "s"(band_hi));
+    asm volatile("" ::"v"(s.x), "v"(s.y), "v"(s.z));   // ... nor the reading point's
+    if ((st_done | st_stall) != 0) return;
     double mine[CP];
 #pragma unroll
     for (int j = 0; j < CP; ++j) mine[j] = 0.0;
     if (q < n) {
-        const float4 s = src[q];
         const float3 p = xf_point(T, s.x, s.y, s.z);
-        const int hv = hint ? (int)hint[q] : 0;
         int lvl;
         const Best b = nearest_group<G>(g, p, sub, -1, &lvl, seg_lds + (threadIdx.x / G) * kSegWords<G>,
                                         hv >= 2 ? hv - 2 : -1);
-        float vals[kSums];
-#pragma unroll
-        for (int k = 0; k < kSums; ++k) vals[k] = 0.f;
-        float w = 0.f;
+        float w = 0.f, dd = INFINITY;
+        uint32_t code_a[CP / 4] = {}, code_c[CP / 4] = {};
         int cls = 2;  // 0: certainly kept, 1: band, 2: dropped / unmatched
+        bool keep = false;   // certainly kept with a non-zero weight: contributes to the sums in this launch
+        // the group's segment list is free again: its first 8 words become the factor table E (see ProdCode)
+        uint32_t* const etab = seg_lds + (threadIdx.x / G) * kSegWords<G>;
         if (b.pos >= 0) {
-            const float dd = b.d2;
-            vals[29] = 1.f;
+            dd = b.d2;
             w = 1.f;
             if (f.use_maxdist && !(dd <= f.outlier_max_d2)) w = 0.f;
             const float4 nn = tgt_nrm[b.pos];
+            const float4 tq = g.pts[b.pos];   // requested with the normal (only kept points use it: one round trip less)
+            // factor codes of the CP components this lane owns (same batch; 64 bytes shared by every wave)
+#pragma unroll
+            for (int wi = 0; wi < CP / 4; ++wi) {
+                code_a[wi] = reinterpret_cast<const uint32_t*>(kProdCode.a)[sub * (CP / 4) + wi];
+                code_c[wi] = reinterpret_cast<const uint32_t*>(kProdCode.c)[sub * (CP / 4) + wi];
+            }
             if (f.use_normal) {
                 const float4 sn = src_nrm[q];
                 const float3 nr = normalize3(xf_rot(T, sn.x, sn.y, sn.z));
@@ -106,15 +157,37 @@ k_iter_fused(const float4* __restrict__ src, const float4* __restrict__ src_nrm,
                 if (val < f.cos_max_angle) w = 0.f;
             }
             cls = dd < band_lo ? 0 : (dd < band_hi ? 1 : 2);
-            if (cls == 0) vals[31] = 1.f;   // counts towards n_below (rank bookkeeping is independent of w)
-            if (w != 0.f && cls != 2) {
-                const float4 tq = g.pts[b.pos];
-                p2pl_products(p, tq, nn, w, vals);
-                vals[28] = 1.f;
-                vals[30] = dd;
+            keep = w != 0.f && cls == 0;
+            if (keep) {
+                // F = [p x n ; n], r = (p - q) . n: lane 0 of the group publishes them, every lane then forms only the
+                // CP products it owns (the weight is 0 or 1 here, so w * F_a * F_c == F_a * F_c exactly)
+                float a = p.y * nn.z, bq = p.z * nn.y;
+                const float F0 = a - bq;
+                a = p.z * nn.x; bq = p.x * nn.z;
+                const float F1 = a - bq;
+                a = p.x * nn.y; bq = p.y * nn.x;
+                const float F2 = a - bq;
+                const float dx = p.x - tq.x, dy = p.y - tq.y, dz = p.z - tq.z;
+                float r = dx * nn.x;
+                float t2 = dy * nn.y;
+                r = r + t2;
+                t2 = dz * nn.z;
+                r = r + t2;
+                if (sub == 0) {
+                    *reinterpret_cast<float4*>(etab) = make_float4(F0, F1, F2, nn.x);
+                    *reinterpret_cast<float4*>(etab + 4) = make_float4(nn.y, nn.z, r, 1.f);
+                }
             }
             if (cls == 1 && sub == 0) {
                 // band record: decided by the update kernel
+                float vals[kSums];
+#pragma unroll
+                for (int k = 0; k < kSums; ++k) vals[k] = 0.f;
+                if (w != 0.f) {
+                    p2pl_products(p, tq, nn, w, vals);
+                    vals[28] = 1.f;
+                    vals[30] = dd;
+                }
                 const unsigned slot = atomicAdd(&it->band_count, 1u);
                 if (slot < (unsigned)band_cap) {
 #pragma unroll
@@ -131,18 +204,25 @@ k_iter_fused(const float4* __restrict__ src, const float4* __restrict__ src_nrm,
             if (hint) hint[q] = (uint8_t)(lvl + 1);
             if (w_out) w_out[q] = (cls == 2) ? 0.f : w;   // band points: provisional, patched by the update kernel
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // E written by lane 0, read by the whole group (same wave)
+        __builtin_amdgcn_wave_barrier();
         // certainly-kept contributions: lane `sub` owns components sub*CP .. sub*CP+CP-1
-        if (cls == 1) {
-#pragma unroll
-            for (int k = 0; k < 29; ++k) vals[k] = 0.f;   // deferred
-            vals[30] = 0.f;
-        }
 #pragma unroll
         for (int j = 0; j < CP; ++j) {
             float v = 0.f;
-#pragma unroll
-            for (int sIdx = 0; sIdx < G; ++sIdx)
-                if (sub == sIdx) v = vals[sIdx * CP + j];
+            if (keep) {
+                const uint32_t oa = (code_a[j / 4] >> (8 * (j & 3))) & 0xffu, oc = (code_c[j / 4] >> (8 * (j & 3))) & 0xffu;
+                const float U = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(etab) + oa);
+                const float V = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(etab) + oc);
+                v = U * V;
+            }
+            if (j >= CP - 4 && sub == G - 1) {   // components 28..31: kept, matched, kept d2, below-band counts
+                const int jj = j - (CP - 4);
+                v = jj == 0 ? (keep ? 1.f : 0.f)
+                  : jj == 1 ? (b.pos >= 0 ? 1.f : 0.f)
+                  : jj == 2 ? (keep ? dd : 0.f)
+                            : ((b.pos >= 0 && cls == 0) ? 1.f : 0.f);   // rank bookkeeping is independent of w
+            }
             mine[j] = (double)v;
         }
     }
