@@ -51,20 +51,28 @@ k_match_g8(const float4* __restrict__ src, int64_t n, const IterState* __restric
            uint32_t* __restrict__ hist2_to_zero, uint8_t* __restrict__ hint, int shift0, int debug, int n_blocks) {
     __shared__ uint32_t sh[2048];
     __shared__ uint32_t seg_lds[(256 / G) * kSegWords<G>];
-    if (it->done) return;
+    const int lb = xcd_block(n_blocks);
+    const int64_t tid = lb * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t q = lb < n_blocks ? (tid / G) : n;
+    const int sub = (int)(tid & (G - 1));
+    // reading point and hint are requested before the state is looked at (one batch of loads instead of two dependent
+    // round trips: see k_iter_fused); unconditional loads from clamped addresses
+    const int64_t qc = q < n ? q : n - 1;
+    const float4 s = src[qc];
+    const uint8_t hraw = *(hint ? hint + qc : reinterpret_cast<const uint8_t*>(src));
+    const int st_done = it->done;
     const Xf T = load_xf(it);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) asm volatile("" ::"s"(T.m[k]));
+    asm volatile("" ::"v"(s.x), "v"(s.y), "v"(s.z));
+    if (st_done) return;
     if (hist2_to_zero && blockIdx.x == 0)
         for (int k = threadIdx.x; k < 2048; k += blockDim.x) hist2_to_zero[k] = 0;
     if (hist0) {
         for (int k = threadIdx.x; k < 2048; k += blockDim.x) sh[k] = 0;
         __syncthreads();
     }
-    const int lb = xcd_block(n_blocks);
-    const int64_t tid = lb * (int64_t)blockDim.x + threadIdx.x;
-    const int64_t q = lb < n_blocks ? (tid / G) : n;
-    const int sub = (int)(tid & (G - 1));
     if (q < n) {
-        const float4 s = src[q];
         const float3 p = xf_point(T, s.x, s.y, s.z);
         if (debug & 4) {  // timing experiment: fixed cost of the launch + reading load only
             if (sub == 0) {
@@ -77,7 +85,7 @@ k_match_g8(const float4* __restrict__ src, int64_t n, const IterState* __restric
         // back within its radius even when the previous search needed a large box -- hints otherwise decay by only one
         // level per iteration; measured -2 % on C2).  hint h >= 2: the last search ended at regular level h-1 -> if the
         // halo cannot answer, continue one regular level below that.
-        const int hv = hint ? (int)hint[q] : 0;
+        const int hv = hint ? (int)hraw : 0;
         int lvl;
         const Best b = nearest_group<G>(g, p, sub, -1, &lvl, seg_lds + (threadIdx.x / G) * kSegWords<G>,
                                         hv >= 2 ? hv - 2 : -1);
