@@ -20,4 +20,6 @@ python tools/tools_timeline.py $OUT/timeline > $OUT/timeline.txt
 # target-side preparation (crop + fp64->fp32 + build), 5 M points; and the plain bench line of this build
 python tools/tools_target_prep.py 5000000 > $OUT/target_prep.log 2>&1
 python bench.py > $OUT/bench_plain.json 2> $OUT/bench_plain.err
+# duration of the two search kernels against the reading size (fixed cost of a launch vs cost per point)
+python tools/tools_scaling.py > $OUT/scaling.txt 2>&1
 python tools/summarise_profiles.py $OUT

@@ -72,9 +72,8 @@ if nst:
         for r in rows:
             r["Name"] = r["Name"][:100]
             w.writerow(r)
-    for line in open(os.path.join(out, "normals.log")):
-        if line.startswith(("GPU", "CPU")):
-            open(os.path.join(dst, "r01_normals_1M_k10_line.txt"), "a").write(line)
+    with open(os.path.join(dst, "r01_normals_1M_k10_line.txt"), "w") as fh:
+        fh.writelines(l for l in open(os.path.join(out, "normals.log")) if l.startswith(("GPU", "CPU")))
 tp = os.path.join(out, "target_prep.log")
 if os.path.exists(tp):
     with open(os.path.join(dst, "r01_target_prep_5M_line.txt"), "w") as fh:
@@ -87,4 +86,7 @@ if os.path.exists(bp):
 tl = os.path.join(out, "timeline.txt")
 if os.path.exists(tl):
     shutil.copy(tl, os.path.join(dst, "r01_registration_timeline.txt"))
+sc = os.path.join(out, "scaling.txt")
+if os.path.exists(sc):
+    shutil.copy(sc, os.path.join(dst, "r01_search_kernels_vs_reading_size.txt"))
 print(json.dumps(summary, indent=1))
