@@ -120,17 +120,12 @@ struct SelectState {
 
 // Block-wide (256 threads): bin b with cum[b] <= rank < cum[b+1] over hist[0..nb), nb <= 2048.
 // Returns through LDS: out[0] = bin, out[1] = rank inside the bin, out[2] = total count.
-__device__ __forceinline__ void block_pick256(const uint32_t* __restrict__ hist, int nb, uint32_t rank,
-                                              uint32_t* wave_tot /*[4]*/, uint32_t* out /*[3]*/) {
+__device__ __forceinline__ void block_pick256_regs(const uint32_t (&loc)[8], uint32_t rank, uint32_t* wave_tot /*[4]*/,
+                                                   uint32_t* out /*[3]*/) {
     const int t = threadIdx.x;
-    uint32_t loc[8];
     uint32_t sum = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int bin = t * 8 + k;
-        loc[k] = bin < nb ? hist[bin] : 0u;
-        sum += loc[k];
-    }
+    for (int k = 0; k < 8; ++k) sum += loc[k];
     uint32_t incl = sum;
     const int lane = t & 63, wave = t >> 6;
     for (int o = 1; o < 64; o <<= 1) {
@@ -163,6 +158,25 @@ __device__ __forceinline__ void block_pick256(const uint32_t* __restrict__ hist,
     __syncthreads();
 }
 
+// This thread's 8 bins of a 2048-entry histogram (two 16-byte loads; every select histogram is allocated with 2048 entries)
+__device__ __forceinline__ void load_hist8(const uint32_t* __restrict__ hist, uint32_t (&loc)[8]) {
+    const uint4 a = reinterpret_cast<const uint4*>(hist)[threadIdx.x * 2];
+    const uint4 b = reinterpret_cast<const uint4*>(hist)[threadIdx.x * 2 + 1];
+    loc[0] = a.x; loc[1] = a.y; loc[2] = a.z; loc[3] = a.w;
+    loc[4] = b.x; loc[5] = b.y; loc[6] = b.z; loc[7] = b.w;
+}
+
+__device__ __forceinline__ void block_pick256(const uint32_t* __restrict__ hist, int nb, uint32_t rank,
+                                              uint32_t* wave_tot /*[4]*/, uint32_t* out /*[3]*/) {
+    uint32_t loc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int bin = threadIdx.x * 8 + k;
+        loc[k] = bin < nb ? hist[bin] : 0u;
+    }
+    block_pick256_regs(loc, rank, wave_tot, out);
+}
+
 // Matches.cpp:82-86: index = size()*quantile evaluated in float, truncated; quantile == 1 -> maximum.
 __device__ __forceinline__ uint32_t trim_rank(uint32_t total, float ratio) {
     if (total == 0) return 0;
@@ -179,17 +193,34 @@ k_select_level(const float* __restrict__ d2, int64_t n, int level, int shift0, f
                uint32_t* __restrict__ hist_out, uint32_t* __restrict__ to_zero, SelectState* st,
                const IterState* __restrict__ it) {
     __shared__ uint32_t sh[2048];
-    if (it->done) return;
     __shared__ uint32_t wave_tot[4];
     __shared__ uint32_t pick[3];
+    // Everything the kernel reads is requested in ONE batch before the state is tested: this thread's first kPre
+    // distances, its 8 bins of the previous level's histogram and the select state (the kernel is a chain of
+    // dependent round trips otherwise: done -> histogram -> state -> distances).
+    constexpr int kPre = 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    uint32_t pre[kPre];
+#pragma unroll
+    for (int u = 0; u < kPre; ++u) {
+        const int64_t i = i0 + u * stride;
+        pre[u] = __float_as_uint(d2[i < n ? i : n - 1]);
+    }
+    uint32_t loc[8];
+    load_hist8(hist_prev, loc);
+    const int st_done = it->done;
+    const uint32_t st_rank = st->rank, st_prefix = st->prefix;
+    asm volatile("" ::"v"(pre[0]), "v"(pre[1]), "v"(pre[2]), "v"(pre[3]));
+    asm volatile("" ::"v"(loc[0]), "v"(loc[4]), "s"(st_rank), "s"(st_prefix));
+    if (st_done) return;
     for (int k = threadIdx.x; k < 2048; k += blockDim.x) sh[k] = 0;
     uint32_t prefix, rank_in;
     if (level == 1) {
         // total count of finite distances = sum of hist0
-        block_pick256(hist_prev, 2048, 0xffffffffu, wave_tot, pick);
+        block_pick256_regs(loc, 0xffffffffu, wave_tot, pick);
         const uint32_t total = pick[2];
         __syncthreads();
-        block_pick256(hist_prev, 2048, trim_rank(total, ratio), wave_tot, pick);
+        block_pick256_regs(loc, trim_rank(total, ratio), wave_tot, pick);
         prefix = pick[0] << shift0;
         rank_in = pick[1];
         if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -199,20 +230,23 @@ k_select_level(const float* __restrict__ d2, int64_t n, int level, int shift0, f
             if (total == 0) st->limit = INFINITY;
         }
     } else {
-        block_pick256(hist_prev, 2048, st->rank, wave_tot, pick);
-        prefix = st->prefix | (pick[0] << (shift0 - 11));
+        block_pick256_regs(loc, st_rank, wave_tot, pick);
+        prefix = st_prefix | (pick[0] << (shift0 - 11));
         rank_in = pick[1];
     }
     __syncthreads();
     const int s1 = shift0 - 11;  // low bit of the level-1 digit; level 2 = the s1 lowest bits
     const uint32_t mask = level == 1 ? ~((1u << shift0) - 1u) : ~((1u << s1) - 1u);
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const uint32_t u = __float_as_uint(d2[i]);
+    auto count = [&](uint32_t u) {
         if (u != 0x7f800000u && (u & mask) == prefix) {
             const uint32_t b = level == 1 ? ((u >> s1) & 2047u) : (u & ((1u << s1) - 1u));
             atomicAdd(&sh[b], 1u);
         }
-    }
+    };
+#pragma unroll
+    for (int u = 0; u < kPre; ++u)
+        if (i0 + u * stride < n) count(pre[u]);
+    for (int64_t i = i0 + kPre * stride; i < n; i += stride) count(__float_as_uint(d2[i]));
     __syncthreads();
     for (int k = threadIdx.x; k < 2048; k += blockDim.x)
         if (sh[k]) atomicAdd(&hist_out[k], sh[k]);
@@ -236,10 +270,24 @@ __global__ void __launch_bounds__(256)
 k_hist_level0(const float* __restrict__ d2, int64_t n, int shift0, uint32_t* __restrict__ hist,
               const IterState* __restrict__ it) {
     __shared__ uint32_t sh[2048];
-    if (it->done) return;
+    // this thread's first kPre distances travel with the state (one round trip instead of two)
+    constexpr int kPre = 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    uint32_t pre[kPre];
+#pragma unroll
+    for (int u = 0; u < kPre; ++u) {
+        const int64_t i = i0 + u * stride;
+        pre[u] = __float_as_uint(d2[i < n ? i : n - 1]);
+    }
+    const int st_done = it->done;
+    asm volatile("" ::"v"(pre[0]), "v"(pre[1]), "v"(pre[2]), "v"(pre[3]));
+    if (st_done) return;
     for (int k = threadIdx.x; k < 2048; k += blockDim.x) sh[k] = 0;
     __syncthreads();
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+#pragma unroll
+    for (int u = 0; u < kPre; ++u)
+        if (i0 + u * stride < n && pre[u] != 0x7f800000u) atomicAdd(&sh[pre[u] >> shift0], 1u);
+    for (int64_t i = i0 + kPre * stride; i < n; i += stride) {
         const uint32_t u = __float_as_uint(d2[i]);
         if (u != 0x7f800000u) atomicAdd(&sh[u >> shift0], 1u);
     }
@@ -337,43 +385,65 @@ k_linearize_p2pl(const float4* __restrict__ src, const float4* __restrict__ src_
                  const float4* __restrict__ tgt_nrm, FilterCfg f, SelectState* __restrict__ st,
                  const uint32_t* __restrict__ hist2, uint32_t* __restrict__ hist1_to_zero, int shift0,
                  float* __restrict__ w_out, double* __restrict__ partials) {
-    if (it->done) return;
+    // One batch for everything that does not depend on the match: match position, distance, reading point and normal
+    // of this thread's point, the pose, the select state and this thread's 8 bins of the last radix level; then ONE
+    // more batch for the matched point and its normal.  (It was a chain of six dependent round trips: done -> state ->
+    // histogram -> position -> normal -> target point.)
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t ic = i < n ? i : n - 1;
+    const int ps_raw = pos[ic];
+    const float dd = d2[ic];
+    const float4 s = src[ic];
+    const float4 sn = *(f.use_normal ? src_nrm + ic : src + ic);
+    uint32_t loc[8];
+    load_hist8(hist2, loc);
+    const int st_done = it->done;
     const Xf T = load_xf(it);
+    const uint32_t st_nfin = st->n_finite, st_pad0 = st->pad[0], st_pad1 = st->pad[1];
+    const float st_limit = st->limit;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) asm volatile("" ::"s"(T.m[k]));
+    asm volatile("" ::"s"(st_nfin), "s"(st_pad0), "s"(st_pad1), "s"(st_limit));
+    asm volatile("" ::"v"(ps_raw), "v"(dd), "v"(s.x), "v"(sn.x), "v"(loc[0]), "v"(loc[4]));
+    if (st_done) return;
+    const int ps = i < n ? ps_raw : -1;
+    const int psc = ps >= 0 ? ps : 0;
+    const float4 nn_ld = tgt_nrm[psc];
+    const float4 q_ld = tgt[psc];
     // trimmed-quantile limit: last radix level, re-derived by every workgroup (f.use_trim == 2),
     // or taken from the state as given by the caller (f.use_trim == 1: distributed path)
     float limit = INFINITY;
     if (f.use_trim == 2) {
         __shared__ uint32_t wave_tot[4];
         __shared__ uint32_t pick[3];
-        if (st->n_finite != 0) {
-            block_pick256(hist2, 1 << (shift0 - 11), st->pad[1], wave_tot, pick);
-            limit = __uint_as_float(st->pad[0] | pick[0]);
+        if (st_nfin != 0) {
+            const int nb = 1 << (shift0 - 11);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if ((int)threadIdx.x * 8 + k >= nb) loc[k] = 0u;
+            block_pick256_regs(loc, st_pad1, wave_tot, pick);
+            limit = __uint_as_float(st_pad0 | pick[0]);
         }
         if (blockIdx.x == 0) {
             if (threadIdx.x == 0) st->limit = limit;
             for (int k = threadIdx.x; k < 2048; k += blockDim.x) hist1_to_zero[k] = 0;
         }
     } else if (f.use_trim == 1) {
-        limit = st->limit;
+        limit = st_limit;
     }
     double v[kSums];
 #pragma unroll
     for (int k = 0; k < kSums; ++k) v[k] = 0.0;
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i < n) {
-        const int ps = pos[i];
-        const float dd = d2[i];
         float w = 0.f;
         if (ps >= 0) {
             v[29] = 1.0;
             w = 1.f;
             if (f.use_maxdist && !(dd <= f.outlier_max_d2)) w = 0.f;
             if (f.use_trim && !(dd <= limit)) w = 0.f;
-            const float4 s = src[i];
             const float3 p = xf_point(T, s.x, s.y, s.z);
-            const float4 nn = (f.debug & 1) ? make_float4(0.f, 0.f, 1.f, 0.f) : tgt_nrm[ps];
+            const float4 nn = (f.debug & 1) ? make_float4(0.f, 0.f, 1.f, 0.f) : nn_ld;
             if (f.use_normal) {
-                const float4 sn = src_nrm[i];
                 const float3 nr = normalize3(xf_rot(T, sn.x, sn.y, sn.z));
                 const float3 nt = normalize3(make_float3(nn.x, nn.y, nn.z));
                 float a = nr.x * nt.x;
@@ -384,7 +454,7 @@ k_linearize_p2pl(const float4* __restrict__ src, const float4* __restrict__ src_
                 if (val < f.cos_max_angle) w = 0.f;
             }
             if (w != 0.f) {
-                const float4 q = (f.debug & 1) ? make_float4(s.x, s.y, s.z, 0.f) : tgt[ps];
+                const float4 q = (f.debug & 1) ? make_float4(s.x, s.y, s.z, 0.f) : q_ld;
                 float F[6];
                 float a = p.y * nn.z, b = p.z * nn.y;
                 F[0] = a - b;
@@ -439,23 +509,31 @@ k_linearize_gicp(const float4* __restrict__ src, const float4* __restrict__ src_
                  const IterState* __restrict__ it,
                  const int* __restrict__ pos, const float* __restrict__ d2, const float4* __restrict__ tgt,
                  const float4* __restrict__ tgt_cov, float* __restrict__ w_out, double* __restrict__ partials) {
-    if (it->done) return;
+    // one batch for what does not depend on the match (position, reading point, its covariance, pose), one for the
+    // matched point and its covariance (see k_linearize_p2pl)
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t ic = i < n ? i : n - 1;
+    const int ps_raw = pos[ic];
+    const float4 s = src[ic];
+    const float4 a0 = src_cov[2 * ic], a1 = src_cov[2 * ic + 1];
+    const int st_done = it->done;
     const Xf T = load_xf(it);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) asm volatile("" ::"s"(T.m[k]));
+    asm volatile("" ::"v"(ps_raw), "v"(s.x), "v"(a0.x), "v"(a1.x));
+    if (st_done) return;
     double v[kSums];
 #pragma unroll
     for (int k = 0; k < kSums; ++k) v[k] = 0.0;
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i < n) {
-        const int ps = pos[i];
+        const int ps = ps_raw;
         float w = 0.f;
         if (ps >= 0) {
             w = 1.f;
-            const float4 s = src[i];
             const float3 tp = xf_point(T, s.x, s.y, s.z);
             const float4 q = tgt[ps];
-            const double r[3] = {(double)q.x - (double)tp.x, (double)q.y - (double)tp.y, (double)q.z - (double)tp.z};
-            const float4 a0 = src_cov[2 * i], a1 = src_cov[2 * i + 1];
             const float4 b0 = tgt_cov[2 * (int64_t)ps], b1 = tgt_cov[2 * (int64_t)ps + 1];
+            const double r[3] = {(double)q.x - (double)tp.x, (double)q.y - (double)tp.y, (double)q.z - (double)tp.z};
             const double Cp[9] = {a0.x, a0.y, a0.z, a0.y, a0.w, a1.x, a0.z, a1.x, a1.y};
             const double Cq[9] = {b0.x, b0.y, b0.z, b0.y, b0.w, b1.x, b0.z, b1.x, b1.y};
             double R[9];
