@@ -46,28 +46,35 @@ static reg_status prepare_rowmajor(reg_handle* h, const float* T_init_row, const
     const bool p2pl = h->prm.cost == REG_COST_P2PL;
     // centroid sums -> (device) centroid + T0; the host copy arrives later through the pinned staging buffer and is
     // only needed for the final composition (R10), so nothing here waits for the device
-    HIPCHK(h, h->s_misc.reserve(256));
+    HIPCHK(h, h->s_misc.reserve(256));   // allocated and cleared when the handle was created
     HIPCHK(h, h->s_prep.reserve(sizeof(PrepState)));
+    // Centroid sums of a single-GPU registration alternate between two slots of s_misc (words 8.. and 16..): the
+    // prepare kernel of THIS registration clears the slot the NEXT one accumulates into, so no memset launch is needed
+    // (slot 0 belongs to reg_dist_centroid_sums, which clears it itself).
+    unsigned long long* sums = h->s_misc.as<unsigned long long>();
+    unsigned long long* sums_next = nullptr;
     if (p2pl && !c_override && n_global <= 0) {
-        HIPCHK(h, hipMemsetAsync(h->s_misc.p, 0, 3 * sizeof(unsigned long long), h->stream));
+        sums = h->s_misc.as<unsigned long long>() + (h->cent_slot ? 16 : 8);
+        sums_next = h->s_misc.as<unsigned long long>() + (h->cent_slot ? 8 : 16);
+        h->cent_slot ^= 1;
         const int blocks = (int)std::min<int64_t>(1024, (n + 255) / 256);
-        k_centroid_sums<<<blocks, 256, 0, h->stream>>>(h->s_raw.as<float>(), h->s_stride, n,
-                                                       h->s_misc.as<unsigned long long>());
+        k_centroid_sums<<<blocks, 256, 0, h->stream>>>(h->s_raw.as<float>(), h->s_stride, n, sums);
     }
     pmark("centroid");
-    Xf4 Ti;
-    std::memcpy(Ti.m, T_init_row, 64);
-    k_make_T0<<<1, 64, 0, h->stream>>>(h->s_misc.as<unsigned long long>(), n_global > 0 ? n_global : n,
-                                       make_float3(h->c_ref[0], h->c_ref[1], h->c_ref[2]), Ti, p2pl ? 1 : 0,
-                                       c_override ? 1 : 0,
-                                       c_override ? make_float3(c_override[0], c_override[1], c_override[2])
-                                                  : make_float3(0.f, 0.f, 0.f),
-                                       h->s_prep.as<PrepState>(), h->d_prep_host);
+    PrepArgs pa;
+    pa.sums = sums;
+    pa.sums_to_clear = sums_next;
+    pa.n = n_global > 0 ? n_global : n;
+    pa.c_ref = make_float3(h->c_ref[0], h->c_ref[1], h->c_ref[2]);
+    std::memcpy(pa.T_init.m, T_init_row, 64);
+    pa.centre = p2pl ? 1 : 0;
+    pa.use_override = c_override ? 1 : 0;
+    pa.c_override = c_override ? make_float3(c_override[0], c_override[1], c_override[2]) : make_float3(0.f, 0.f, 0.f);
+    pa.out = h->s_prep.as<PrepState>();
+    pa.host_out = h->d_prep_host;
     h->prep_pending = true;
-    pmark("T0+copy");
-    const PrepState* ps = h->s_prep.as<PrepState>();
     k_prepare_source<<<grid_for(n), 256, 0, h->stream>>>(
-        h->s_raw.as<float>(), h->s_stride, (p2pl && h->has_snrm) ? h->s_nrm_raw.as<float>() : nullptr, h->s_nstride, n, ps,
+        h->s_raw.as<float>(), h->s_stride, (p2pl && h->has_snrm) ? h->s_nrm_raw.as<float>() : nullptr, h->s_nstride, n, pa,
         p2pl ? 1 : 0, h->perm, h->s_xyz.as<float4>(), (p2pl && h->has_snrm) ? h->s_nrm.as<float4>() : nullptr,
         h->i_hint.as<uint8_t>(), h->i_hist.as<uint32_t>(), h->i_acc.as<double>(), kAccRows * kSums);
     if (!p2pl)
@@ -343,7 +350,7 @@ static void sums_to_system(const double* sums, bool p2pl, float* H, float* b) {
 // R10: T = T_refIn_refMean * T_iter * T_refMean_readMean * T_readIn_readMean^-1 (ICP.cpp:1345); GICP: T_iter itself
 static void compose_rowmajor(reg_handle* h, const float* T_iter, float* Tout_row, bool later_kernel_reported = false) {
     if (h->prep_pending) {
-        // k_make_T0 wrote PrepState into mapped host memory (system-scope fence); it is visible once that kernel has
+        // k_prepare_source wrote PrepState into mapped host memory (system-scope fence); it is visible once that kernel has
         // completed: either a later kernel of the same stream has already reported through the mirror, or wait here
         if (!later_kernel_reported) (void)hipStreamSynchronize(h->stream);
         std::memcpy(h->c_read, h->h_prep->c_read, 12);

@@ -102,6 +102,7 @@ struct reg_handle {
     DevBuf s_prep;
     PrepState* h_prep = nullptr;      // mapped pinned host copy of the device-side preparation state
     PrepState* d_prep_host = nullptr; // device view of h_prep
+    int cent_slot = 0;                // which centroid-sum slot of s_misc the next single-GPU registration uses
     bool prep_pending = false;        // h_prep not yet folded into c_read / T0
     DevBuf i_hint, s_keys, s_keys2, s_perm, s_perm2, s_tmp, i_tmpf;
     const uint32_t* perm = nullptr;   // slot -> input index (null: identity)
@@ -210,7 +211,8 @@ reg_status reg_create(const reg_params* p, reg_handle** out) {
         hipHostMalloc((void**)&h->h_iter, sizeof(IterState), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&h->h_prep, sizeof(PrepState), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&h->d_prep_host, h->h_prep, 0) != hipSuccess ||
-        h->i_iter.reserve(sizeof(IterState)) != hipSuccess) {
+        h->i_iter.reserve(sizeof(IterState)) != hipSuccess || h->s_misc.reserve(256) != hipSuccess ||
+        hipMemset(h->s_misc.p, 0, 256) != hipSuccess) {   // centroid-sum slots start cleared (see prepare_rowmajor)
         h->err = "hipHostMalloc / hipMalloc of the iteration state failed";
         *out = h;
         return REG_DEVICE_ERROR;

@@ -13,36 +13,40 @@ struct PrepState {
     float pad;
     float T0[16];   // row-major
 };
-// sums: integer centroid sums (NC1); c_override != null: use the given (global, multi-GPU) centroid instead.
-__global__ void k_make_T0(const unsigned long long* __restrict__ sums, int64_t n, float3 c_ref, Xf4 T_init, int centre,
-                          int use_override, float3 c_override, PrepState* __restrict__ out,
-                          PrepState* __restrict__ host_out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    float c[3] = {0.f, 0.f, 0.f};
-    if (centre) {
-        if (use_override) {
-            c[0] = c_override.x; c[1] = c_override.y; c[2] = c_override.z;
+// Reading centroid (integer sums, NC1; or the given global centroid of a multi-GPU reading) and the pre-transform
+// T0 = T_refIn_refMean^-1 * T_init * T_readIn_readMean (ICP.cpp:966-984).  Evaluated redundantly by every thread of
+// k_prepare_source (uniform inputs, ~150 flops): a separate one-thread kernel cost a launch (2 us + a 4-6 us gap while
+// the host enqueued the next one) in front of every registration.
+struct PrepArgs {
+    const unsigned long long* sums;   // 3 fixed-point sums (2^16 per unit)
+    unsigned long long* sums_to_clear;   // the slot the NEXT registration accumulates into (or null)
+    int64_t n;                        // points behind the sums (the whole reading)
+    float3 c_ref;
+    Xf4 T_init;
+    int centre, use_override;
+    float3 c_override;
+    PrepState* out;
+    PrepState* host_out;
+};
+__device__ __forceinline__ void prep_compute(const PrepArgs& a, float* c /*[3]*/, float* T0 /*[16]*/) {
+    c[0] = c[1] = c[2] = 0.f;
+    if (a.centre) {
+        if (a.use_override) {
+            c[0] = a.c_override.x; c[1] = a.c_override.y; c[2] = a.c_override.z;
         } else {
-            for (int k = 0; k < 3; ++k) c[k] = (float)((double)(long long)sums[k] / (65536.0 * (double)n));
+            for (int k = 0; k < 3; ++k) c[k] = (float)((double)(long long)a.sums[k] / (65536.0 * (double)a.n));
         }
     }
-    float A[16], B[16], tmp[16], T0[16];
+    float A[16], B[16], tmp[16];
     m4_identity(A);
     m4_identity(B);
-    if (centre) {
-        A[3] = -c_ref.x; A[7] = -c_ref.y; A[11] = -c_ref.z;   // T_refIn_refMean^-1
-        B[3] = c[0]; B[7] = c[1]; B[11] = c[2];               // T_readIn_readMean
-        m4_mul(A, T_init.m, tmp);
+    if (a.centre) {
+        A[3] = -a.c_ref.x; A[7] = -a.c_ref.y; A[11] = -a.c_ref.z;   // T_refIn_refMean^-1
+        B[3] = c[0]; B[7] = c[1]; B[11] = c[2];                     // T_readIn_readMean
+        m4_mul(A, a.T_init.m, tmp);
         m4_mul(tmp, B, T0);
     } else {
-        for (int i = 0; i < 16; ++i) T0[i] = T_init.m[i];
-    }
-    for (int k = 0; k < 3; ++k) out->c_read[k] = c[k];
-    for (int i = 0; i < 16; ++i) out->T0[i] = T0[i];
-    if (host_out) {   // mapped pinned copy for the final composition on the host (a D2H memcpy costs ~50 us of host time)
-        for (int k = 0; k < 3; ++k) host_out->c_read[k] = c[k];
-        for (int i = 0; i < 16; ++i) host_out->T0[i] = T0[i];
-        __threadfence_system();
+        for (int i = 0; i < 16; ++i) T0[i] = a.T_init.m[i];
     }
 }
 
@@ -76,21 +80,33 @@ __global__ void k_source_keys(const float* __restrict__ xyz, int64_t stride, int
 // Also clears the per-registration scratch (level hints, trimmed-quantile histograms, accumulator replicas), so the
 // registration needs no memset launches.
 __global__ void k_prepare_source(const float* __restrict__ xyz, int64_t stride, const float* __restrict__ nrm,
-                                 int64_t nrm_stride, int64_t n, const PrepState* __restrict__ ps, int centre,
+                                 int64_t nrm_stride, int64_t n, PrepArgs pa, int centre,
                                  const uint32_t* __restrict__ perm, float4* __restrict__ out_xyz,
                                  float4* __restrict__ out_nrm, uint8_t* __restrict__ hint, uint32_t* __restrict__ hist,
                                  double* __restrict__ acc, int n_acc) {
+    float c[3], T0f[16];
+    prep_compute(pa, c, T0f);
     if (blockIdx.x == 0) {
         for (int k = threadIdx.x; k < 3 * 2048; k += blockDim.x) hist[k] = 0u;
         for (int k = threadIdx.x; k < n_acc; k += blockDim.x) acc[k] = 0.0;
+        if (threadIdx.x < 3 && pa.sums_to_clear) pa.sums_to_clear[threadIdx.x] = 0ull;
+        if (threadIdx.x == 0) {
+            for (int k = 0; k < 3; ++k) pa.out->c_read[k] = c[k];
+            for (int i = 0; i < 16; ++i) pa.out->T0[i] = T0f[i];
+            if (pa.host_out) {   // mapped pinned copy for the final composition on the host (a D2H memcpy costs ~50 us of host time)
+                for (int k = 0; k < 3; ++k) pa.host_out->c_read[k] = c[k];
+                for (int i = 0; i < 16; ++i) pa.host_out->T0[i] = T0f[i];
+                __threadfence_system();
+            }
+        }
     }
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     hint[i] = 0;
     Xf T0;
 #pragma unroll
-    for (int k = 0; k < 12; ++k) T0.m[k] = ps->T0[k];
-    const float cx = ps->c_read[0], cy = ps->c_read[1], cz = ps->c_read[2];
+    for (int k = 0; k < 12; ++k) T0.m[k] = T0f[k];
+    const float cx = c[0], cy = c[1], cz = c[2];
     const int64_t src = perm ? (int64_t)perm[i] : i;
     const float* p = xyz + src * stride;
     float x = p[0], y = p[1], z = p[2];

@@ -6,7 +6,7 @@ f = glob.glob(d + '/**/*kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 prep = [i for i, r in enumerate(rows) if 'k_prepare_source' in r['Kernel_Name']]
-i0 = prep[-1] - 3 if prep else max(0, len(rows) - 80)
+i0 = prep[-1] - 1 if prep else max(0, len(rows) - 80)   # k_centroid_sums, k_prepare_source, state copy, iterations
 t0 = int(rows[i0]['Start_Timestamp'])
 prev_end = t0
 busy = 0
