@@ -28,7 +28,7 @@ static reg_status check_ready(reg_handle* h, bool need_prepared) {
 // n_global > 0: the centroid sums in s_misc have already been produced (reg_dist_centroid_sums) and reduced over all
 // ranks by the caller; they describe n_global points.
 static reg_status prepare_rowmajor(reg_handle* h, const float* T_init_row, const float* c_override = nullptr,
-                                   int64_t n_global = 0) {
+                                   int64_t n_global = 0, const IterState* init_state = nullptr) {
     reg_status s = check_ready(h, false);
     if (s != REG_OK) return s;
     if (!m4_is_finite(T_init_row)) {
@@ -73,10 +73,18 @@ static reg_status prepare_rowmajor(reg_handle* h, const float* T_init_row, const
     pa.out = h->s_prep.as<PrepState>();
     pa.host_out = h->d_prep_host;
     h->prep_pending = true;
+    StateInit si;
+    si.dst = nullptr;
+    if (init_state) {
+        si.init = *init_state;
+        si.dst = h->i_iter.as<IterState>();
+    } else {
+        std::memset(&si.init, 0, sizeof(si.init));
+    }
     k_prepare_source<<<grid_for(n), 256, 0, h->stream>>>(
         h->s_raw.as<float>(), h->s_stride, (p2pl && h->has_snrm) ? h->s_nrm_raw.as<float>() : nullptr, h->s_nstride, n, pa,
         p2pl ? 1 : 0, h->perm, h->s_xyz.as<float4>(), (p2pl && h->has_snrm) ? h->s_nrm.as<float4>() : nullptr,
-        h->i_hint.as<uint8_t>(), h->i_hist.as<uint32_t>(), h->i_acc.as<double>(), kAccRows * kSums);
+        h->i_hint.as<uint8_t>(), h->i_hist.as<uint32_t>(), h->i_acc.as<double>(), kAccRows * kSums, si);
     if (!p2pl)
         k_pack_cov<<<grid_for(n), 256, 0, h->stream>>>(h->s_cov_raw.as<float>(), n, h->perm, h->s_cov.as<float4>());
     pmark("prepare_source");
@@ -89,11 +97,10 @@ static reg_status prepare_rowmajor(reg_handle* h, const float* T_init_row, const
 // ---- iteration state ---------------------------------------------------------------------------------
 
 // (Re)initialise the device-side iteration state: pose T (row-major), mode and checker configuration.
-static reg_status init_iter_state(reg_handle* h, const float* T_row, int update) {
-    IterState* st = h->h_iter;
-    // the pinned staging copy may still be in flight from the previous call: wait for THAT copy only (an event
-    // recorded right behind it), not for everything else enqueued on the stream
-    if (h->iter_copy_pending) HIPCHK(h, hipEventSynchronize(h->ev_iter));
+// Host part: fills *st (plain memory).  reg_register hands the result to k_prepare_source as a kernel argument (the
+// state then reaches the device with the launch that is enqueued anyway: a pinned-staging hipMemcpyAsync + event
+// cost ~20 us of host time in front of the first search kernel); the other entry points copy it (init_iter_state).
+static reg_status build_iter_state(reg_handle* h, const float* T_row, int update, IterState* st) {
     std::memset(st, 0, sizeof(IterState));
     for (int i = 0; i < 16; ++i) {
         st->T[i] = T_row[i];
@@ -134,6 +141,16 @@ static reg_status init_iter_state(reg_handle* h, const float* T_row, int update)
         for (int k = 0; k < 12; ++k) st->xicp_Trd[k] = Trd[k];
         h->xicp_pending = true;
     }
+    return REG_OK;
+}
+
+static reg_status init_iter_state(reg_handle* h, const float* T_row, int update) {
+    IterState* st = h->h_iter;
+    // the pinned staging copy may still be in flight from the previous call: wait for THAT copy only (an event
+    // recorded right behind it), not for everything else enqueued on the stream
+    if (h->iter_copy_pending) HIPCHK(h, hipEventSynchronize(h->ev_iter));
+    reg_status s = build_iter_state(h, T_row, update, st);
+    if (s != REG_OK) return s;
     HIPCHK(h, hipMemcpyAsync(h->i_iter.p, st, sizeof(IterState), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipEventRecord(h->ev_iter, h->stream));
     h->iter_copy_pending = true;
@@ -432,18 +449,20 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
             fprintf(stderr, "[o3dreg] register %-14s t=%.1fus\n", what,
                     std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_reg0).count());
     };
-    reg_status s = prepare_rowmajor(h, Ti);
-    if (s != REG_OK) return s;
-    rmark("prepared");
     const bool p2pl = h->prm.cost == REG_COST_P2PL;
     float T_start[16];
     if (p2pl)
         m4_identity(T_start);
     else
         std::memcpy(T_start, Ti, 64);
-    s = init_iter_state(h, T_start, 1);
+    std::memcpy(h->T_init, Ti, 64);   // the R8x frame change in the state is derived from it (prepare sets it again)
+    IterState st0;
+    reg_status s = build_iter_state(h, T_start, 1, &st0);
     if (s != REG_OK) return s;
     rmark("iter state");
+    s = prepare_rowmajor(h, Ti, nullptr, 0, &st0);   // the state travels as an argument of the prepare kernel
+    if (s != REG_OK) return s;
+    rmark("prepared");
     h->profiling = h->prm.profile_loop != 0;
     // loop_ms: HIP events only when profiling (record + synchronise cost ~20 us of host time per registration);
     // otherwise the host clock around the loop -- the loop ends when the last update kernel's mirror has arrived

@@ -79,14 +79,26 @@ __global__ void k_source_keys(const float* __restrict__ xyz, int64_t stride, int
 // reading' = T0 * (p - c_read), normals' = R0 * n  (ICP.cpp:966-984); slot i holds input point perm[i]
 // Also clears the per-registration scratch (level hints, trimmed-quantile histograms, accumulator replicas), so the
 // registration needs no memset launches.
+// Initial iteration state handed over as a kernel argument (dst == null: the caller copies the state itself).
+struct StateInit {
+    IterState init;
+    IterState* dst;
+};
+
 __global__ void k_prepare_source(const float* __restrict__ xyz, int64_t stride, const float* __restrict__ nrm,
                                  int64_t nrm_stride, int64_t n, PrepArgs pa, int centre,
                                  const uint32_t* __restrict__ perm, float4* __restrict__ out_xyz,
                                  float4* __restrict__ out_nrm, uint8_t* __restrict__ hint, uint32_t* __restrict__ hist,
-                                 double* __restrict__ acc, int n_acc) {
+                                 double* __restrict__ acc, int n_acc, const StateInit si) {
     float c[3], T0f[16];
     prep_compute(pa, c, T0f);
     if (blockIdx.x == 0) {
+        if (si.dst) {
+            static_assert(sizeof(IterState) % 4 == 0, "word copy");
+            const uint32_t* w = reinterpret_cast<const uint32_t*>(&si.init);
+            for (int k = threadIdx.x; k < (int)(sizeof(IterState) / 4); k += blockDim.x)
+                reinterpret_cast<uint32_t*>(si.dst)[k] = w[k];
+        }
         for (int k = threadIdx.x; k < 3 * 2048; k += blockDim.x) hist[k] = 0u;
         for (int k = threadIdx.x; k < n_acc; k += blockDim.x) acc[k] = 0.0;
         if (threadIdx.x < 3 && pa.sums_to_clear) pa.sums_to_clear[threadIdx.x] = 0ull;
