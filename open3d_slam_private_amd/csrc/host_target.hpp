@@ -40,6 +40,7 @@ struct EnvSwitches {
     bool stamps = false;        // O3D_STAMPS: in-kernel cycle stamps of the update kernel
     int lookahead = 2;          // O3D_KAHEAD
     float settle_tol = 0.25f;   // O3D_SETTLE
+    float halo_ratio = 1.5f;    // O3D_HALO_RATIO: halo-bin edge in units of the brick-table bin edge (tuning sweeps)
     void read() {
         trace = getenv("O3D_TRACE") != nullptr;
         event_timing = getenv("O3D_EVENT_TIMING") != nullptr;
@@ -48,6 +49,7 @@ struct EnvSwitches {
         stamps = getenv("O3D_STAMPS") != nullptr;
         if (const char* v = getenv("O3D_KAHEAD")) lookahead = std::max(1, atoi(v));
         if (const char* v = getenv("O3D_SETTLE")) settle_tol = (float)atof(v);
+        if (const char* v = getenv("O3D_HALO_RATIO")) halo_ratio = std::min(4.0f, std::max(0.5f, (float)atof(v)));
     }
 };
 
@@ -423,7 +425,7 @@ static reg_status build_halo(reg_handle* h, float c, const float bmin[3], const 
     g.use_halo = 0;
     g.level_after_halo = 0;
     if (h->prm.disable_halo == 1) return REG_OK;  // A/B experiments
-    const float ch = 1.5f * c;
+    const float ch = h->env.halo_ratio * c;
     const float abs_margin = 4e-7f * (1.0f + max_abs);
     const float rho_h = 0.25f * ch * (1.0f - 4e-3f) - 2.f * abs_margin;
     if (!(rho_h > 0.f)) return REG_OK;
