@@ -101,6 +101,9 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
     __shared__ uint32_t pick[2];
     __shared__ float s_limit;
     __shared__ uint32_t bd2[kBandCap];
+    constexpr int kDirectCap = 256;   // bands up to this many records are ranked directly (4 threads per record)
+    __shared__ __attribute__((aligned(16))) uint32_t bdk[kDirectCap];
+    __shared__ uint32_t dcnt[kDirectCap];
     __shared__ __attribute__((aligned(16))) uint32_t mir_w[(sizeof(HostMirror) + 3) / 4];
     __shared__ uint32_t small[64];
     __shared__ uint32_t s_cnt, s_csel, s_need_radix;
@@ -262,89 +265,120 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
             // (u - u_lo) * 2048 / (u_hi - u_lo) spreads them over 2048 bins (about one value per bin); the bin that
             // holds rank r is then resolved by direct ranking.  Crowded bin (> 64 equal-ish values): radix levels.
             const uint32_t u_lo = __float_as_uint(s_band_lo), u_hi = __float_as_uint(s_band_hi);
-            // order-preserving key without integer division: trunc(double(u - u_lo) * 2048 / span) (monotone in u)
-            const double kscale = 2048.0 / (double)(u_hi > u_lo ? u_hi - u_lo : 1u);
             uint32_t rank = k - n_below, prefix = 0;
-            sx1 = __builtin_amdgcn_s_memtime();
-            for (int i = threadIdx.x; i < 2048 + 64; i += 1024) hist[i] = 0;
-            if (threadIdx.x == 0) {
-                s_cnt = 0;
-                s_need_radix = 0;
-            }
-            lds_barrier();   // LDS-only barrier: the record loads issued above stay in flight
-            for (uint32_t i = threadIdx.x; i < n_band; i += 1024) {
-                const uint32_t key = (uint32_t)((double)(bd2[i] - u_lo) * kscale);
-                const uint32_t kk = min(key, 2047u);
-                atomicAdd(&hist[kk + (kk >> 5)], 1u);   // +1 pad per 32 bins: lane-contiguous reads below are conflict-free
-            }
-            lds_barrier();   // LDS-only barrier: the record loads issued above stay in flight
-            sx2 = __builtin_amdgcn_s_memtime();
-            {
-                // block-wide pick (2 bins per thread, padded index): exclusive scan of the 2048 counts
-                const uint32_t b0 = 2u * threadIdx.x, b1 = b0 + 1u;
-                const uint32_t h0 = hist[b0 + (b0 >> 5)], h1 = hist[b1 + (b1 >> 5)];
-                const uint32_t loc = h0 + h1;
-                uint32_t incl = loc;
-                const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const uint32_t v = __shfl_up(incl, o);
-                    if (ln >= o) incl += v;
-                }
-                if (ln == 63) wave_tot[wv] = incl;
+            // Small band (the usual case once the limit has settled: ~200 records): direct ranking on unique keys
+            // ((u - u_lo) << 8 | record), four threads per record, each counting a quarter of the band with one
+            // compare per pair -- three LDS barriers instead of the six of the histogram path below.
+            const bool direct = n_band <= (uint32_t)kDirectCap && u_hi > u_lo && (u_hi - u_lo) < (1u << 24);
+            if (direct) {
+                sx1 = __builtin_amdgcn_s_memtime();
+                const uint32_t n_pad = (n_band + 15u) & ~15u;   // whole uint4 per quarter; padding keys compare as "not below"
+                if (threadIdx.x < n_pad)
+                    bdk[threadIdx.x] = threadIdx.x < n_band ? (((my_d2[0] - u_lo) << 8) | threadIdx.x) : 0xffffffffu;
+                if (threadIdx.x < (uint32_t)kDirectCap) dcnt[threadIdx.x] = 0u;
                 lds_barrier();
-                uint32_t base = 0;
-#pragma unroll
-                for (int w = 0; w < 16; ++w) base += (w < wv) ? wave_tot[w] : 0u;
-                const uint32_t excl = base + incl - loc;
-                if (loc && rank >= excl && rank < excl + loc) {   // exactly one thread
-                    const bool first = rank < excl + h0;
-                    pick[0] = first ? b0 : b1;
-                    pick[1] = first ? rank - excl : rank - excl - h0;
-                    s_csel = first ? h0 : h1;
+                sx2 = __builtin_amdgcn_s_memtime();
+                {
+                    const uint32_t i = threadIdx.x & (kDirectCap - 1), qd = threadIdx.x / kDirectCap;   // qd is wave-uniform
+                    if (i < n_band) {
+                        const uint32_t e = bdk[i];
+                        const uint32_t qlen = n_pad / 4u, j0 = qd * qlen;
+                        uint32_t rr = 0;
+                        for (uint32_t j = j0; j < j0 + qlen; j += 4) {
+                            const uint4 o = *reinterpret_cast<const uint4*>(&bdk[j]);
+                            rr += (o.x < e ? 1u : 0u) + (o.y < e ? 1u : 0u) + (o.z < e ? 1u : 0u) + (o.w < e ? 1u : 0u);
+                        }
+                        atomicAdd(&dcnt[i], rr);
+                    }
                 }
                 lds_barrier();
-                const uint32_t bsel = pick[0], rsel = pick[1], csel = s_csel;
-                if (csel <= 64u) {
-                    // gather the picked bin's values (all threads), rank them directly (wave 0)
-                    for (uint32_t i = threadIdx.x; i < n_band; i += 1024) {
-                        const uint32_t key = min((uint32_t)((double)(bd2[i] - u_lo) * kscale), 2047u);
-                        if (key == bsel) small[atomicAdd(&s_cnt, 1u)] = bd2[i];
+                if (threadIdx.x < n_band && dcnt[threadIdx.x] == rank) s_limit = __uint_as_float(my_d2[0]);
+                lds_barrier();
+                sx3 = __builtin_amdgcn_s_memtime();
+            } else {
+                // order-preserving key without integer division: trunc(double(u - u_lo) * 2048 / span) (monotone in u)
+                const double kscale = 2048.0 / (double)(u_hi > u_lo ? u_hi - u_lo : 1u);
+                sx1 = __builtin_amdgcn_s_memtime();
+                for (int i = threadIdx.x; i < 2048 + 64; i += 1024) hist[i] = 0;
+                if (threadIdx.x == 0) {
+                    s_cnt = 0;
+                    s_need_radix = 0;
+                }
+                lds_barrier();   // LDS-only barrier: the record loads issued above stay in flight
+                for (uint32_t i = threadIdx.x; i < n_band; i += 1024) {
+                    const uint32_t key = (uint32_t)((double)(bd2[i] - u_lo) * kscale);
+                    const uint32_t kk = min(key, 2047u);
+                    atomicAdd(&hist[kk + (kk >> 5)], 1u);   // +1 pad per 32 bins: lane-contiguous reads below are conflict-free
+                }
+                lds_barrier();   // LDS-only barrier: the record loads issued above stay in flight
+                sx2 = __builtin_amdgcn_s_memtime();
+                {
+                    // block-wide pick (2 bins per thread, padded index): exclusive scan of the 2048 counts
+                    const uint32_t b0 = 2u * threadIdx.x, b1 = b0 + 1u;
+                    const uint32_t h0 = hist[b0 + (b0 >> 5)], h1 = hist[b1 + (b1 >> 5)];
+                    const uint32_t loc = h0 + h1;
+                    uint32_t incl = loc;
+                    const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    #pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const uint32_t v = __shfl_up(incl, o);
+                        if (ln >= o) incl += v;
+                    }
+                    if (ln == 63) wave_tot[wv] = incl;
+                    lds_barrier();
+                    uint32_t base = 0;
+    #pragma unroll
+                    for (int w = 0; w < 16; ++w) base += (w < wv) ? wave_tot[w] : 0u;
+                    const uint32_t excl = base + incl - loc;
+                    if (loc && rank >= excl && rank < excl + loc) {   // exactly one thread
+                        const bool first = rank < excl + h0;
+                        pick[0] = first ? b0 : b1;
+                        pick[1] = first ? rank - excl : rank - excl - h0;
+                        s_csel = first ? h0 : h1;
                     }
                     lds_barrier();
-                    if (threadIdx.x < csel) {
-                        const uint32_t e = small[threadIdx.x];
-                        uint32_t rr = 0;
-                        for (uint32_t j = 0; j < csel; ++j) {
-                            const uint32_t o = small[j];
-                            rr += (o < e || (o == e && j < threadIdx.x)) ? 1u : 0u;
+                    const uint32_t bsel = pick[0], rsel = pick[1], csel = s_csel;
+                    if (csel <= 64u) {
+                        // gather the picked bin's values (all threads), rank them directly (wave 0)
+                        for (uint32_t i = threadIdx.x; i < n_band; i += 1024) {
+                            const uint32_t key = min((uint32_t)((double)(bd2[i] - u_lo) * kscale), 2047u);
+                            if (key == bsel) small[atomicAdd(&s_cnt, 1u)] = bd2[i];
                         }
-                        if (rr == rsel) s_limit = __uint_as_float(e);
+                        lds_barrier();
+                        if (threadIdx.x < csel) {
+                            const uint32_t e = small[threadIdx.x];
+                            uint32_t rr = 0;
+                            for (uint32_t j = 0; j < csel; ++j) {
+                                const uint32_t o = small[j];
+                                rr += (o < e || (o == e && j < threadIdx.x)) ? 1u : 0u;
+                            }
+                            if (rr == rsel) s_limit = __uint_as_float(e);
+                        }
+                    } else if (threadIdx.x == 0) {
+                        s_need_radix = 1;
                     }
-                } else if (threadIdx.x == 0) {
-                    s_need_radix = 1;
                 }
-            }
-            lds_barrier();   // LDS-only barrier: the record loads issued above stay in flight
-            sx3 = __builtin_amdgcn_s_memtime();
-            if (s_need_radix) {   // crowded bin (many equal distances): plain 3-level radix select, all threads
-            for (int level = 0; level < 3; ++level) {
-                for (int i = threadIdx.x; i < 2048; i += 1024) hist[i] = 0;
-                __syncthreads();
-                const uint32_t mask = level == 0 ? 0u : (level == 1 ? 0xffe00000u : 0xfffffc00u);
-                for (uint32_t i = threadIdx.x; i < n_band; i += 1024) {
-                    const uint32_t u = bd2[i];
-                    if ((u & mask) == prefix)
-                        atomicAdd(&hist[level == 0 ? (u >> 21) : (level == 1 ? ((u >> 10) & 2047u) : (u & 1023u))], 1u);
+                lds_barrier();   // LDS-only barrier: the record loads issued above stay in flight
+                sx3 = __builtin_amdgcn_s_memtime();
+                if (s_need_radix) {   // crowded bin (many equal distances): plain 3-level radix select, all threads
+                for (int level = 0; level < 3; ++level) {
+                    for (int i = threadIdx.x; i < 2048; i += 1024) hist[i] = 0;
+                    __syncthreads();
+                    const uint32_t mask = level == 0 ? 0u : (level == 1 ? 0xffe00000u : 0xfffffc00u);
+                    for (uint32_t i = threadIdx.x; i < n_band; i += 1024) {
+                        const uint32_t u = bd2[i];
+                        if ((u & mask) == prefix)
+                            atomicAdd(&hist[level == 0 ? (u >> 21) : (level == 1 ? ((u >> 10) & 2047u) : (u & 1023u))], 1u);
+                    }
+                    __syncthreads();
+                    block_pick1024(hist, level == 2 ? 1024 : 2048, rank, wave_tot, pick);
+                    prefix |= pick[0] << (level == 0 ? 21 : (level == 1 ? 10 : 0));
+                    rank = pick[1];
+                    __syncthreads();
                 }
+                if (threadIdx.x == 0) s_limit = __uint_as_float(prefix);
                 __syncthreads();
-                block_pick1024(hist, level == 2 ? 1024 : 2048, rank, wave_tot, pick);
-                prefix |= pick[0] << (level == 0 ? 21 : (level == 1 ? 10 : 0));
-                rank = pick[1];
-                __syncthreads();
-            }
-            if (threadIdx.x == 0) s_limit = __uint_as_float(prefix);
-            __syncthreads();
+                }
             }
             stB = __builtin_amdgcn_s_memtime();
             const float limit = s_limit;
