@@ -90,7 +90,7 @@ typedef struct {
     int32_t profile_loop;       /* 1: bracket every search kernel of reg_register with HIP events (perturbs the loop slightly) */
     int32_t match_variant;      /* 0: 8 lanes per reading point + level hints (default); 1: one lane per point; 2: 8 lanes, no hints; 3: as 0 with the level-0 histogram fused into the match kernel */
     /* experiment switches (all 0 in production; used by the A/B scripts under tools/) */
-    int32_t debug_flags;        /* ablation bits for timing experiments: 4, 8 change results (tests only); 32 = hash instead of the dense brick directory (results unchanged) */
+    int32_t debug_flags;        /* ablation bits for timing experiments: 4, 8 change results (tests only); 32 = hash instead of the dense brick directory, 64 = histogram select for every trimmed band (results unchanged) */
     int32_t disable_halo;       /* 1: no halo-bin level 0 */
     int32_t lanes_per_point;    /* 0 = default (8); 4 */
     int32_t disable_fused;      /* 1: every iteration on the generic (select-based) path */

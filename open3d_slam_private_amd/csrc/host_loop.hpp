@@ -123,7 +123,7 @@ static reg_status build_iter_state(reg_handle* h, const float* T_row, int update
     st->use_trim = (h->prm.cost == REG_COST_P2PL && h->prm.use_trimmed) ? 1 : 0;
     st->trim_ratio = h->prm.trim_ratio;
     st->band_cap = kBandCap;
-    st->debug_narrow_band = (h->prm.debug_flags & 8) ? 1 : 0;
+    st->debug_narrow_band = ((h->prm.debug_flags & 8) ? 1 : 0) | ((h->prm.debug_flags & 64) ? 2 : 0);   // bit 1: no direct band ranking
     h->xicp_pending = false;
     for (int k = 0; k < 6; ++k) st->xicp_flags[k] = 1;
     if (h->prm.use_xicp && h->prm.cost == REG_COST_P2PL && update) {

@@ -269,7 +269,8 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
             // Small band (the usual case once the limit has settled: ~200 records): direct ranking on unique keys
             // ((u - u_lo) << 8 | record), four threads per record, each counting a quarter of the band with one
             // compare per pair -- three LDS barriers instead of the six of the histogram path below.
-            const bool direct = n_band <= (uint32_t)kDirectCap && u_hi > u_lo && (u_hi - u_lo) < (1u << 24);
+            const bool direct = n_band <= (uint32_t)kDirectCap && u_hi > u_lo && (u_hi - u_lo) < (1u << 24) &&
+                                !(sit->debug_narrow_band & 2);   // debug_flags & 64: histogram path for every band (tests)
             if (direct) {
                 sx1 = __builtin_amdgcn_s_memtime();
                 const uint32_t n_pad = (n_band + 15u) & ~15u;   // whole uint4 per quarter; padding keys compare as "not below"
@@ -440,7 +441,7 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
     // one by one inside the serial section, every access cost its own ~100-cycle LDS round trip (3.4 k cycles measured
     // before the pose update even started).
     const float r_limit_last = sit->limit_last, r_limit_sel = s_limit;
-    const int r_dbg_narrow = sit->debug_narrow_band, r_update = sit->update, r_xstage = sit->xicp_stage;
+    const int r_dbg_narrow = sit->debug_narrow_band & 1, r_update = sit->update, r_xstage = sit->xicp_stage;
     const int r_fixed = sit->fixed_iters, r_iters = sit->iterations;
     int r_xnc = sit->xicp_nc;
     const unsigned r_band_count = sit->band_count;

@@ -28,7 +28,7 @@ struct IterState {
     float limit_prev;         // ... and of the one before
     unsigned int band_count;  // records appended to the band buffer in this iteration
     unsigned int band_cap;
-    int debug_narrow_band;
+    int debug_narrow_band;    // test hooks: bit 0 forces band mispredictions, bit 1 disables the direct band ranking
     // R8x (X-ICP localizability, OptimizedEqualityConstraints)
     int xicp_stage;           // 0: off / analysed, 1: analysis pending (first iteration), 2: sums being collected
     int xicp_nc;              // number of non-localizable directions (constraints)

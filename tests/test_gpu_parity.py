@@ -415,14 +415,50 @@ def test_fused_and_generic_iterations_give_the_same_registration(seed):
     select-based iteration: same iteration count, same final pose, same last-iteration weights."""
     sc = synth.make_scene(15000, 150000, seed=seed)
     Tg, rg, idg, d2g, wg = _register(sc, fixed_iters=12, disable_fused=1)
-    Tf, rf, idf, d2f, wf = _register(sc, fixed_iters=12)
-    assert rf.n_band_stalls == 0
-    dt, dr = synth.pose_error(Tf, Tg)
-    assert dt <= 1e-6 and dr <= 1e-6, (dt, dr)
-    assert rf.n_inliers == rg.n_inliers and rf.n_matched == rg.n_matched
-    assert np.array_equal(idf, idg) and np.array_equal(d2f.view(np.uint32), d2g.view(np.uint32))
-    assert np.array_equal(wf, wg)
-    assert abs(rf.error - rg.error) <= 1e-9 * rg.error
+    for flags in (0, 64):   # 64: histogram select for every band (small bands are otherwise ranked directly)
+        Tf, rf, idf, d2f, wf = _register(sc, fixed_iters=12, debug_flags=flags)
+        assert rf.n_band_stalls == 0
+        dt, dr = synth.pose_error(Tf, Tg)
+        assert dt <= 1e-6 and dr <= 1e-6, (dt, dr)
+        assert rf.n_inliers == rg.n_inliers and rf.n_matched == rg.n_matched
+        assert np.array_equal(idf, idg) and np.array_equal(d2f.view(np.uint32), d2g.view(np.uint32))
+        assert np.array_equal(wf, wg)
+        assert abs(rf.error - rg.error) <= 1e-9 * rg.error
+
+
+def _lattice_scene(n_side, spacing, top_fraction):
+    """Lattice reading 2-3 cm above a lattice plane: the squared distances form a few tight clusters; `top_fraction`
+    of the points sit one centimetre higher, so the trimmed quantile (0.9) falls inside that cluster."""
+    import types
+    g = np.arange(200, dtype=np.float32) * np.float32(0.05)
+    tx, ty = np.meshgrid(g, g, indexing="ij")
+    tgt = np.stack([tx.ravel(), ty.ravel(), np.zeros(tx.size, np.float32)], axis=1).astype(np.float32)
+    tnrm = np.tile(np.array([[0, 0, 1]], np.float32), (tgt.shape[0], 1))
+    s = np.arange(n_side, dtype=np.float32) * np.float32(spacing) + np.float32(2.0)
+    sx, sy = np.meshgrid(s, s, indexing="ij")
+    rng = np.random.default_rng(5)
+    high = (rng.random(sx.size) < top_fraction).astype(np.float32)
+    src = np.stack([sx.ravel() + np.float32(0.012), sy.ravel() - np.float32(0.007),
+                    np.float32(0.02) + np.float32(0.01) * high], axis=1).astype(np.float32)
+    snrm = np.tile(np.array([[0, 0, 1]], np.float32), (src.shape[0], 1))
+    return types.SimpleNamespace(tgt_xyz=tgt, tgt_nrm=tnrm, src_xyz=src, src_nrm=snrm)
+
+
+@pytest.mark.parametrize("n_side,spacing", [(13, 0.15), (60, 0.1)])
+def test_fused_band_select_with_clustered_distances(n_side, spacing):
+    """Band select of the update kernel on (near-)equal distances (a lattice reading over a lattice plane: the band
+    holds a few to a few dozen records with many exact ties), through both of its paths: direct ranking on unique keys
+    and (debug_flags 64) the histogram select.  The fused iterations must reproduce the select-based ones bit for bit."""
+    sc = _lattice_scene(n_side, spacing, 0.2)
+    Tg, rg, idg, d2g, wg = _register(sc, fixed_iters=10, disable_fused=1)
+    for flags in (0, 64):   # direct ranking / histogram select (crowded bins -> radix levels)
+        Tf, rf, idf, d2f, wf = _register(sc, fixed_iters=10, debug_flags=flags)
+        assert rf.iterations == rg.iterations == 10
+        dt, dr = synth.pose_error(Tf, Tg)
+        assert dt <= 1e-6 and dr <= 1e-6, (dt, dr)
+        assert rf.n_inliers == rg.n_inliers and rf.n_matched == rg.n_matched
+        assert np.array_equal(idf, idg) and np.array_equal(d2f.view(np.uint32), d2g.view(np.uint32))
+        assert np.array_equal(wf, wg)
 
 
 def test_band_misprediction_stalls_and_is_repaired_exactly():
