@@ -415,8 +415,10 @@ def test_fused_and_generic_iterations_give_the_same_registration(seed):
     select-based iteration: same iteration count, same final pose, same last-iteration weights."""
     sc = synth.make_scene(15000, 150000, seed=seed)
     Tg, rg, idg, d2g, wg = _register(sc, fixed_iters=12, disable_fused=1)
-    for flags in (0, 64):   # 64: histogram select for every band (small bands are otherwise ranked directly)
-        Tf, rf, idf, d2f, wf = _register(sc, fixed_iters=12, debug_flags=flags)
+    # 64: histogram select for every band (small bands are otherwise ranked directly); 4 lanes per reading point: the
+    # other instantiation of the fused kernel (8 components per lane)
+    for flags, lanes in ((0, 0), (64, 0), (0, 4)):
+        Tf, rf, idf, d2f, wf = _register(sc, fixed_iters=12, debug_flags=flags, lanes_per_point=lanes)
         assert rf.n_band_stalls == 0
         dt, dr = synth.pose_error(Tf, Tg)
         assert dt <= 1e-6 and dr <= 1e-6, (dt, dr)
