@@ -96,7 +96,7 @@ k_iter_fused(const float4* __restrict__ src, const float4* __restrict__ src_nrm,
     constexpr int CP = kSums / G;   // components owned by each lane of a group
     static_assert(CP % 4 == 0 && CP >= 4, "a lane owns whole code words (4 components each)");
     __shared__ double sh[4][kSums];
-    __shared__ uint32_t seg_lds[(256 / G) * kSegWords<G>];
+    __shared__ __attribute__((aligned(16))) uint32_t seg_lds[(256 / G) * kSegWords<G>];
     const int lb = xcd_block(n_blocks);
     const int64_t tid = lb * (int64_t)blockDim.x + threadIdx.x;
     const int64_t q = lb < n_blocks ? (tid / G) : n;

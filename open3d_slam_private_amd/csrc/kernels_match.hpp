@@ -40,7 +40,7 @@ k_match(const float4* __restrict__ src, int64_t n, const IterState* __restrict__
 
 // LDS words per group for the wide level scan (segment starts + exclusive offsets + sentinel)
 template <int G>
-constexpr int kSegWords = 2 * G * kSegPerLane + 2;
+constexpr int kSegWords = (2 * G * kSegPerLane + 2 + 3) & ~3;   // a multiple of 4 words: 16-byte aligned rows (the fused kernel reuses a row as float4s)
 
 // Cooperative variant: G (8 or 4) lanes per reading point (256/G points per 256-thread workgroup).
 // `hint` (one byte per point, may be null) carries the terminating level of the previous iteration.
@@ -50,7 +50,7 @@ k_match_g8(const float4* __restrict__ src, int64_t n, const IterState* __restric
            float* __restrict__ d2, uint32_t* __restrict__ hist0 /* 2048 or null */,
            uint32_t* __restrict__ hist2_to_zero, uint8_t* __restrict__ hint, int shift0, int debug, int n_blocks) {
     __shared__ uint32_t sh[2048];
-    __shared__ uint32_t seg_lds[(256 / G) * kSegWords<G>];
+    __shared__ __attribute__((aligned(16))) uint32_t seg_lds[(256 / G) * kSegWords<G>];
     const int lb = xcd_block(n_blocks);
     const int64_t tid = lb * (int64_t)blockDim.x + threadIdx.x;
     const int64_t q = lb < n_blocks ? (tid / G) : n;
