@@ -334,7 +334,12 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": n_src * bytes_pp,
                          "kernel_ms": kern[dom]["avg_ms"], "launches": kern[dom]["launches"],
-                         "bytes_per_point": bytes_pp},
+                         "bytes_per_point": bytes_pp,
+                         # measured, DESIGN.md section 6: duration = ~11 us fixed (one wave's chain of dependent round
+                         # trips) + 13.5 us per 100 k reading points; VALU -14 % changed it by -1 %
+                         "limiter": "latency of dependent round trips, then Infinity-Cache/HBM fetches of the candidate "
+                                    "records an exact search has to look at (profiles/r01_search_kernel_counters.txt, "
+                                    "profiles/r01_search_kernels_vs_reading_size.txt)"},
             "kernels": kern,
             "roofline_iteration": {"bytes_per_point": ITER_BYTES_PER_POINT,
                                    "achieved_GBs_end_to_end": n_src * ITER_BYTES_PER_POINT * ITERS * args.steps / elapsed / 1e9},
