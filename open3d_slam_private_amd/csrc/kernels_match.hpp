@@ -87,7 +87,7 @@ k_match_g8(const float4* __restrict__ src, int64_t n, const IterState* __restric
         // halo cannot answer, continue one regular level below that.
         const int hv = hint ? (int)hraw : 0;
         int lvl;
-        const Best b = nearest_group<G>(g, p, sub, -1, &lvl, seg_lds + (threadIdx.x / G) * kSegWords<G>,
+        const Best b = nearest_group<G, true>(g, p, sub, -1, &lvl, seg_lds + (threadIdx.x / G) * kSegWords<G>,
                                         hv >= 2 ? hv - 2 : -1);
         if (sub == 0) {
             pos[q] = b.pos;

@@ -300,7 +300,7 @@ __device__ __forceinline__ Best group_min_lazy(const Grid& g, Best b, int gbase)
 // Large radii (first iterations of a registration) are bound by dependent-load rounds: this cuts them roughly in half.
 constexpr int kSegPerLane = 4;
 
-template <int G>
+template <int G, bool kPrune>
 __device__ __forceinline__ void scan_level_wide(const Grid& g, const float3 p, int sub, int gbase, int l,
                                                 uint32_t* seg, Best& best) {
     constexpr int S = kSegPerLane, CAP = G * S;
@@ -319,6 +319,16 @@ __device__ __forceinline__ void scan_level_wide(const Grid& g, const float3 p, i
     const int nrow = nbx * ny;
     const int total = nrow * nz;
     const unsigned gmask = (1u << G) - 1u;
+    // Ball pruning (exact): a bin box holds ~2x the volume of the ball it covers.  Rows whose (y, z) bin interval lies
+    // farther than the box radius from the query are skipped and the others are cut to the x-range the ball reaches,
+    // in BIN units with a slack of kPruneSlack bins per axis that covers the rounding of fl(fl(v - o) * 1/c) for grids
+    // of up to 16384 bins per axis (larger grids: no pruning).  Every reference point within rho_box of the query stays
+    // inside the scanned set, which is all the termination test (best d2 <= rho^2 < rho_box^2) relies on.
+    constexpr float kPruneSlack = 4e-3f;
+    const bool prune = kPrune && g.dimx <= 16384 && g.dimy <= 16384 && g.dimz <= 16384;
+    const float fxq = (p.x - g.ox) * g.inv_c, fyq = (p.y - g.oy) * g.inv_c, fzq = (p.z - g.oz) * g.inv_c;
+    const float rbb = rb * g.inv_c + kPruneSlack;
+    const float rb2 = rbb * rbb;
     for (int base = 0; base < total; base += CAP) {
         // phase 1a: brick ids of this lane's segments (independent loads)
         int bid[S], off[S];
@@ -331,9 +341,19 @@ __device__ __forceinline__ void scan_level_wide(const Grid& g, const float3 p, i
                 const int iz = t / nrow, rem = t - iz * nrow;
                 const int iy = rem / nbx, ix = rem - iy * nbx;
                 const int bx = bx0 + ix, cy = loy + iy, cz = loz + iz;
+                int gx0 = max(lox, bx << kBrickLog2), gx1 = min(hix, (bx << kBrickLog2) + kBrickDim - 1);
+                if (prune) {
+                    const float dyb = fmaxf(fmaxf((float)cy - fyq, fyq - (float)(cy + 1)) - kPruneSlack, 0.f);
+                    const float dzb = fmaxf(fmaxf((float)cz - fzq, fzq - (float)(cz + 1)) - kPruneSlack, 0.f);
+                    const float r2 = rb2 - dyb * dyb - dzb * dzb;
+                    if (r2 < 0.f) continue;   // the whole row lies outside the ball
+                    const float hxb = __builtin_amdgcn_sqrtf(r2) * 1.0001f + kPruneSlack;
+                    gx0 = max(gx0, (int)fminf(fmaxf(floorf(fxq - hxb), 0.f), g.dimx - 1.f));
+                    gx1 = min(gx1, (int)fminf(fmaxf(floorf(fxq + hxb), 0.f), g.dimx - 1.f));
+                    if (gx0 > gx1) continue;
+                }
                 bid[u] = brick_lookup(g, bx, cy >> kBrickLog2, cz >> kBrickLog2);
-                const int x0 = max(lox, bx << kBrickLog2) & (kBrickDim - 1);
-                const int x1 = min(hix, (bx << kBrickLog2) + kBrickDim - 1) & (kBrickDim - 1);
+                const int x0 = gx0 & (kBrickDim - 1), x1 = gx1 & (kBrickDim - 1);
                 off[u] = (((cz & (kBrickDim - 1)) << (2 * kBrickLog2)) | ((cy & (kBrickDim - 1)) << kBrickLog2)) |
                          (x0 << 12) | (x1 << 16);
             }
@@ -410,7 +430,10 @@ __device__ __forceinline__ void scan_level_wide(const Grid& g, const float3 p, i
 // each lane of the group looks up one segment (brick hash probe + two bin-start loads).  Phase 2: the
 // group scans every non-empty segment TOGETHER, lane k reading point s+k, s+k+8, ... -- consecutive
 // 16-byte records, i.e. one or two cache lines per group step instead of one line per lane.
-template <int G>
+// kPrune: ball pruning of the wide level scan (search kernel of the select-based iterations, whose first launches scan
+// large boxes); the fused kernel, whose queries almost always end in the halo level, does without (it would cost it
+// registers beyond the 80 of 6 waves/SIMD).
+template <int G, bool kPrune = false>
 __device__ __forceinline__ Best nearest_group(const Grid& g, float3 p, int sub, int first_level, int* level_out,
                                               uint32_t* seg, int after_halo = -1) {
     Best best;
@@ -456,7 +479,7 @@ __device__ __forceinline__ Best nearest_group(const Grid& g, float3 p, int sub, 
     }
     l = max(max(l, after_halo), 0);   // no halo level (or the query lies outside its grid): the hinted level
     for (; l < g.n_levels; ++l) {
-        scan_level_wide<G>(g, p, sub, gbase, l, seg, best);
+        scan_level_wide<G, kPrune>(g, p, sub, gbase, l, seg, best);
         best = group_min<G>(best);
         const float rw = g.rho[l];
         if (best.pos >= 0 && best.d2 <= rw * rw) break;   // every point within rho was inside the box: exact
