@@ -321,11 +321,12 @@ __device__ __forceinline__ void scan_level_wide(const Grid& g, const float3 p, i
     const unsigned gmask = (1u << G) - 1u;
     // Ball pruning (exact): a bin box holds ~2x the volume of the ball it covers.  Rows whose (y, z) bin interval lies
     // farther than the box radius from the query are skipped and the others are cut to the x-range the ball reaches,
-    // in BIN units with a slack of kPruneSlack bins per axis that covers the rounding of fl(fl(v - o) * 1/c) for grids
-    // of up to 16384 bins per axis (larger grids: no pruning).  Every reference point within rho_box of the query stays
+    // in BIN units with a slack of kPruneSlack bins per axis: the bin coordinate fl(fl(v - o) * 1/c) of a reference point
+    // and of the query each carry a relative error of 2 * 2^-24, i.e. < 1e-3 bins below 8192 bins per axis -- the slack is
+    // twice their sum (larger grids: no pruning).  Every reference point within rho_box of the query stays
     // inside the scanned set, which is all the termination test (best d2 <= rho^2 < rho_box^2) relies on.
     constexpr float kPruneSlack = 4e-3f;
-    const bool prune = kPrune && g.dimx <= 16384 && g.dimy <= 16384 && g.dimz <= 16384;
+    const bool prune = kPrune && g.dimx <= 8192 && g.dimy <= 8192 && g.dimz <= 8192;
     const float fxq = (p.x - g.ox) * g.inv_c, fyq = (p.y - g.oy) * g.inv_c, fzq = (p.z - g.oz) * g.inv_c;
     const float rbb = rb * g.inv_c + kPruneSlack;
     const float rb2 = rbb * rbb;

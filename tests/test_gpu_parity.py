@@ -127,6 +127,34 @@ def test_car_linearize_bit_exact_ids():
     _check_linearize(reg, ref[:, :3], ref[:, 3:6], rd, None, 1.0, 0.85, None)
 
 
+def test_wide_scans_far_from_the_grid_origin_bit_exact_ids():
+    """Ball pruning of the wide level scan works in bin coordinates; their rounding grows with the distance from the
+    grid origin.  A 1.5 km long strip (7500 bins of 0.2 m along x: just below the 8192-bin limit of the pruning) with the
+    reading at its far end, 0.1-0.45 m away from the surface so that the searches need large boxes: correspondence ids,
+    squared distances and weights must still equal the oracle's kd-tree search bit for bit."""
+    rng = np.random.default_rng(11)
+    n_t = 420000
+    tx = (rng.random(n_t) * 1500.0).astype(np.float32)
+    ty = (rng.random(n_t) * 3.0).astype(np.float32)
+    tz = (np.float32(0.3) * np.sin(tx / np.float32(5.0))).astype(np.float32)
+    tgt = np.stack([tx, ty, tz], axis=1).astype(np.float32)
+    tnrm = np.tile(np.array([[0, 0, 1]], np.float32), (n_t, 1))
+    far = np.flatnonzero(tx > 1380.0)
+    pick = rng.choice(far, 6000, replace=False)
+    src = (tgt[pick] + np.array([0.31, 0.17, 0.08], np.float32)
+           + (rng.random((pick.size, 3)) * np.float32(0.25)).astype(np.float32)).astype(np.float32)
+    p = capi.default_params()
+    p.max_dist = 1.0
+    p.cell_size = 0.2
+    reg = capi.Registration(p)
+    reg.set_target(tgt, tnrm)
+    info = reg.target_info()
+    assert info.cell_size == pytest.approx(0.2)
+    reg.set_source(src)
+    reg.prepare(np.eye(4))
+    _check_linearize(reg, tgt, tnrm, src, None, 1.0, 0.85, None)
+
+
 @pytest.mark.parametrize("n_src,n_tgt", [(5000, 50000), (20000, 200000)])
 def test_synth_shipped_chain(n_src, n_tgt):
     sc = synth.make_scene(n_src, n_tgt, seed=1234)
