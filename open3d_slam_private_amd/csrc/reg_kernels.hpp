@@ -310,7 +310,7 @@ __device__ __forceinline__ void scan_level_wide(const Grid& g, const float3 p, i
     // candidate's own distance grown by the same margins: no point farther than the candidate can win, and every point
     // at most as far (ties included) stays inside the box.
     float rb = g.rho_box[l];
-    if (kPrune && best.pos >= 0 && g.rho[l] < INFINITY)
+    if (best.pos >= 0 && g.rho[l] < INFINITY)
         rb = fminf(rb, __builtin_amdgcn_sqrtf(best.d2) * 1.001f + (rb - g.rho[l]));
     const int lox = (int)fminf(fmaxf(bin_coord_f(p.x - rb, g.ox, g.inv_c), 0.f), g.dimx - 1.f);
     const int loy = (int)fminf(fmaxf(bin_coord_f(p.y - rb, g.oy, g.inv_c), 0.f), g.dimy - 1.f);
