@@ -1,26 +1,29 @@
 #!/usr/bin/env python3
 """Headline benchmark: ICP iterations/sec of scan-to-map registration on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|tiny] [--mode strong|weak]
 
-A "step" is ONE registration of the synthetic scan against the synthetic map with exactly
-ITERS (=20) Gauss-Newton iterations of the reference's shipped chain (param/icp.yaml: knn 1, maxDist 0.5,
-TrimmedDist 0.9, SurfaceNormal 1.57, point-to-plane): R2 reading prep + 20 x (R3 transform, R4 exact 1-NN,
-R5 trimmed quantile + normal filter, R7 normal equations, R8 6x6 solve, R9 pose update) + R10.
-Inputs are resident in HBM before the timed region; the target voxel-bin build (== kd-tree build of the
-reference) is excluded on both sides and reported as target_build_ms.
+A "step" is ONE registration of the synthetic scan against the synthetic map with exactly ITERS (=20) Gauss-Newton
+iterations of the reference's chain (param/icp.yaml: knn 1, maxDist 0.5, TrimmedDist 0.9, SurfaceNormal 1.57,
+point-to-plane): R2 reading prep + 20 x (R3 transform, R4 exact 1-NN, R5 trimmed quantile + normal filter, R7 normal
+equations, R8 6x6 solve, R9 pose update) + R10.  Inputs are resident in HBM before the timed region; the target
+voxel-bin build (== kd-tree build of the reference) is excluded on both sides and reported as target_build_ms, the
+per-scan reading upload + ordering as source_prep_ms.
 
-N=1: workload C2 (100k -> 1M points, BASELINE.json configs[1]).
-N>1: WEAK scaling -- every rank holds its own 100k-point slice of an N*100k-point reading (point
-partitioned), the 1M-point map is replicated; per iteration the ranks all-reduce the trimmed-quantile
-histograms and the 32-double (H, b, e, counts) record over RCCL.  `value` counts 100k-point iteration
-units: N_gpus * ITERS * K / t.
+N = 1 (default): workload C3 = 200k -> 5M points, the largest single-GPU configuration of BASELINE.json and the size its
+        metric is quoted on ("100k->5M-pt scan-to-map").  The same line carries, as secondary objects the driver times
+        too: C2 (100k -> 1M), the C4 map on one GPU (whole 200k reading and one rank's 25k slice against the 20M-point
+        map), 8 registrations in flight on 8 HIP streams (C5 analogue), the GICP cost, and the shipped chain with its
+        degeneracyAwareness (R8x) switched on.
+N > 1: workload C4 as BASELINE.json states it: ONE 200k-point reading split into N contiguous slices (200k/N points per
+        rank), the 20M-point map replicated on every GPU, per iteration the ranks exchange the trimmed-quantile data and
+        the 32-double (H, b, e, counts) record over RCCL.  STRONG scaling: `value` = ITERS * K / t, whole-reading
+        iterations per second.  `--mode weak` (explicit) keeps the reading at 200k points PER RANK instead.
 
 Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
-import math
 import os
 import sys
 import time
@@ -32,7 +35,7 @@ sys.path.insert(0, ROOT)
 
 ITERS = 20
 WORKLOADS = {"c2": (100_000, 1_000_000, 1234 + 2), "c3": (200_000, 5_000_000, 1234 + 3),
-             "tiny": (10_000, 100_000, 1234 + 1)}
+             "c4": (200_000, 20_000_000, 1234 + 4), "tiny": (10_000, 100_000, 1234 + 1)}
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 # algorithmic bytes per reading point and launch:
 #   k_match_g8  : src xyz 12 + matched tgt xyz 12 + pos 4 + d2 4 written            = 32
@@ -41,16 +44,114 @@ KERNEL_BYTES_PER_POINT = {"k_match_g8": 32, "k_iter_fused": 48}
 ITER_BYTES_PER_POINT = 64    # P2Pl 48 B + 16 B (id, d2 written and re-read) for the split-kernel variant
 
 
-def cpu_baseline(sc, n_src, threads):
-    """The oracle (faithful C restatement; the reference itself cannot be built here) timed on the host cores:
-    same clouds, same chain, kd-tree build excluded.  Bounded sample: the first `n_src` reading points."""
+def chain_params(capi, device, xicp=0):
+    """The measured chain: the shipped icp.yaml with epsilon 0, fixed 20 iterations; R8x off unless asked."""
+    p = capi.shipped_params()
+    p.fixed_iters = ITERS
+    p.device = device
+    p.use_xicp = xicp
+    return p
+
+
+def cpu_baseline(sc, threads):
+    """The oracle (faithful C restatement; the reference itself cannot be built here) timed on the host cores: same
+    clouds, same chain, same 20 iterations on both legs, kd-tree build excluded.  Returns (figures, T of the OpenMP leg)."""
     from oracle import oracle as orc
     out = {}
-    for name, nt, iters in (("omp", threads, ITERS), ("1t", 1, 4)):
-        _, r = orc.icp_p2pl(sc.tgt_xyz, sc.tgt_nrm, sc.src_xyz[:n_src], sc.src_nrm[:n_src], max_dist=0.5,
-                            trim_ratio=0.9, max_normal_angle=1.57, fixed_iters=iters, n_threads=nt)
-        out[name] = iters / r.loop_seconds
-    return out
+    T_omp = None
+    for name, nt in (("omp", threads), ("1t", 1)):
+        T, r = orc.icp_p2pl(sc.tgt_xyz, sc.tgt_nrm, sc.src_xyz, sc.src_nrm, max_dist=0.5, trim_ratio=0.9,
+                            max_normal_angle=1.57, fixed_iters=ITERS, n_threads=nt)
+        out[name] = ITERS / r.loop_seconds
+        if name == "omp":
+            T_omp = T
+    return out, T_omp
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+class DeviceScene:
+    """A synthetic scene resident in HBM (torch tensors are only the allocation: plumbing)."""
+
+    def __init__(self, torch, dev, sc, lo=0, hi=None, with_cov=False):
+        self.sc = sc
+        self.n_tgt = sc.tgt_xyz.shape[0]
+        hi = sc.src_xyz.shape[0] if hi is None else hi
+        self.n_src = hi - lo
+        self.tgt = torch.from_numpy(sc.tgt_xyz).to(dev)
+        self.tnrm = torch.from_numpy(sc.tgt_nrm).to(dev)
+        self.src = torch.from_numpy(np.ascontiguousarray(sc.src_xyz[lo:hi])).to(dev)
+        self.snrm = torch.from_numpy(np.ascontiguousarray(sc.src_nrm[lo:hi])).to(dev)
+        self.tcov = self.scov = None
+        if with_cov:
+            self.tcov = torch.from_numpy(sc.tgt_cov).to(dev)
+            self.scov = torch.from_numpy(np.ascontiguousarray(sc.src_cov[lo:hi])).to(dev)
+        torch.cuda.synchronize()
+
+    def make_reg(self, capi, p, n_src=None):
+        reg = capi.Registration(p)
+        if p.cost == capi.COST_GICP:
+            reg.set_target_device(self.tgt.data_ptr(), 3, self.n_tgt, None, 3, self.tcov.data_ptr())
+            reg.set_source_device(self.src.data_ptr(), 3, n_src or self.n_src, None, 3, self.scov.data_ptr())
+        else:
+            reg.set_target_device(self.tgt.data_ptr(), 3, self.n_tgt, self.tnrm.data_ptr(), 3)
+            reg.set_source_device(self.src.data_ptr(), 3, n_src or self.n_src, self.snrm.data_ptr(), 3)
+        return reg
+
+
+def time_registrations(torch, reg, T_init, steps, warmup=2):
+    for _ in range(warmup):
+        out = reg.register(T_init)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = reg.register(T_init)
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, out
+
+
+def kernel_profile(capi, ds, local_rank):
+    """One more registration with begin/end HIP events attached to every search-kernel dispatch on the handle's own
+    stream (profile_loop) -> average launch duration over the SAME 20-iteration trajectory the timed region ran;
+    rocprofv3 --kernel-trace of this command must agree."""
+    p = chain_params(capi, local_rank)
+    p.profile_loop = 1
+    preg = ds.make_reg(capi, p)
+    T_init = np.eye(4, dtype=np.float32)
+    preg.register(T_init)
+    _, pres = preg.register(T_init)
+    kern = {}
+    for idx, name in ((0, "k_match_g8"), (1, "k_iter_fused")):
+        if pres.prof_launches[idx]:
+            kern[name] = {"launches": int(pres.prof_launches[idx]), "total_ms": float(pres.prof_ms[idx]),
+                          "avg_ms": float(pres.prof_ms[idx]) / int(pres.prof_launches[idx])}
+    preg.close()
+    return kern
+
+
+def pmc_traffic(workload, dom):
+    """HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the number comes from the
+    committed rocprofv3 --pmc passes of THIS command (tools/collect_profiles.sh; FETCH_SIZE doubled as the gfx950 guide
+    prescribes and as the stream-kernel calibration in that file confirms)."""
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if pj.get("workload", "c2") != workload:
+                continue
+            for kname, kv in pj["kernels"].items():
+                if kname.startswith(dom):
+                    return kv["hbm_bytes_per_launch_corrected"], f"profiles/{name} (2*FETCH_SIZE + WRITE_SIZE, bytes per launch)"
+        except (OSError, KeyError, ValueError):
+            pass
+    return None, None
 
 
 def main():
@@ -58,11 +159,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: c3 on one GPU, c4 (200k -> 20M, reading split over the ranks) on N > 1")
+    ap.add_argument("--mode", default="strong", choices=("strong", "weak"),
+                    help="N > 1 only.  strong (default, = BASELINE config C4): ONE reading split into N slices; "
+                         "weak: every rank holds a full-size slice of an N-times larger reading")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="extra measurement (config 5 analogue): S independent registrations in flight, one handle + "
-                         "HIP stream + host thread each; reported under \"batched\", never as `value`")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary objects (C2, C4 map, batched, GICP, R8x)")
+    ap.add_argument("--streams", type=int, default=8,
+                    help="secondary measurement (config 5 analogue): S independent C2 registrations in flight, one handle "
+                         "+ HIP stream + host thread each; reported under \"batched\", never as `value`")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -76,50 +182,51 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the registration path has no CPU fallback")
-    if os.environ.get("O3D_BENCH_BACKEND", "nccl") != "nccl":
+    backend = os.environ.get("O3D_BENCH_BACKEND", "nccl")   # "gloo": rehearsal of the N>1 path on a 1-GPU box
+    if backend != "nccl":
         local_rank = local_rank % torch.cuda.device_count()   # rehearsal: several ranks share the one GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        backend = os.environ.get("O3D_BENCH_BACKEND", "nccl")   # "gloo": rehearsal of the N>1 path on a 1-GPU box
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
 
-    n_src, n_tgt, seed = WORKLOADS[args.workload]
-    sc = synth.make_scene(n_src * world, n_tgt, seed=seed)
-    lo, hi = rank * n_src, (rank + 1) * n_src
-
-    # inputs resident in HBM before anything is timed
-    d_tgt = torch.from_numpy(sc.tgt_xyz).to(dev)
-    d_tnrm = torch.from_numpy(sc.tgt_nrm).to(dev)
-    d_src = torch.from_numpy(sc.src_xyz[lo:hi]).to(dev)
-    d_snrm = torch.from_numpy(sc.src_nrm[lo:hi]).to(dev)
-    torch.cuda.synchronize()
-
-    p = capi.shipped_params()
-    p.fixed_iters = ITERS
-    p.device = local_rank
-    reg = capi.Registration(p)
-    reg.set_target_device(d_tgt.data_ptr(), 3, n_tgt, d_tnrm.data_ptr(), 3)
-    reg.set_source_device(d_src.data_ptr(), 3, n_src, d_snrm.data_ptr(), 3)
-    info = reg.target_info()
+    force_dist = os.environ.get("O3D_BENCH_FORCE_DIST") == "1"   # rehearsal: N>1 code path with one rank
+    multi = world > 1 or force_dist
+    workload = args.workload or ("c4" if multi else "c3")
+    n_src, n_tgt, seed = WORKLOADS[workload]
+    if multi and args.mode == "weak":
+        sc = synth.make_scene(n_src * world, n_tgt, seed=seed)
+        lo, hi = rank * n_src, (rank + 1) * n_src
+    else:
+        sc = synth.make_scene(n_src, n_tgt, seed=seed)
+        lo, hi = (rank * n_src) // world, ((rank + 1) * n_src) // world
+    n_global = sc.src_xyz.shape[0]
+    n_local = hi - lo
+    ds = DeviceScene(torch, dev, sc, lo, hi)
     T_init = np.eye(4, dtype=np.float32)
 
-    force_dist = os.environ.get("O3D_BENCH_FORCE_DIST") == "1"   # rehearsal: N>1 code path with one rank
-    if world == 1 and not force_dist:
+    p = chain_params(capi, local_rank)
+    reg = capi.Registration(p)
+    loop_kind = None
+    if not multi:
+        reg.set_target_device(ds.tgt.data_ptr(), 3, n_tgt, ds.tnrm.data_ptr(), 3)
+        reg.set_source_device(ds.src.data_ptr(), 3, n_local, ds.snrm.data_ptr(), 3)
+
         def step():
             return reg.register(T_init)
     else:
-        # stream-ordered loop: kernels of the library and RCCL all-reduces share torch's current stream; the host
-        # never synchronises inside a registration (open3d_slam_private_amd/distributed.py)
+        # stream-ordered loop: kernels of the library and RCCL collectives share torch's current stream; the host never
+        # synchronises inside a registration (open3d_slam_private_amd/distributed.py)
         from open3d_slam_private_amd.distributed import (FusedStreamDistributedRegistration,
-                                                         StreamDistributedRegistration)
-        coll_dev = dev
-        reg.set_stream(torch.cuda.current_stream().cuda_stream)
+                                                         StreamDistributedRegistration, _DevArray)
+        reg.set_stream(torch.cuda.current_stream().cuda_stream)    # before any upload: one stream orders everything
+        reg.set_target_device(ds.tgt.data_ptr(), 3, n_tgt, ds.tnrm.data_ptr(), 3)
+        reg.set_source_device(ds.src.data_ptr(), 3, n_local, ds.snrm.data_ptr(), 3)
         sreg = StreamDistributedRegistration(reg, True, ITERS, dist=dist, device=dev)
         ag = None
         if dist is not None and dist.get_backend() != "nccl":      # rehearsal backends: no all_gather_into_tensor
@@ -128,8 +235,6 @@ def main():
                 dist.all_gather(parts, inp)
         freg = FusedStreamDistributedRegistration(reg, True, p.trim_ratio, ITERS, world, rank, dist=dist, device=dev,
                                                   all_gather=ag)
-
-        from open3d_slam_private_amd.distributed import _DevArray
         cent = torch.as_tensor(_DevArray(reg.dist_centroid_sums(), (3,), "<i8"), device=dev)
 
         def prep():
@@ -138,7 +243,7 @@ def main():
             reg.dist_centroid_sums()
             if dist is not None:
                 dist.all_reduce(cent)
-            reg.dist_prepare(T_init, n_src * world)
+            reg.dist_prepare(T_init, n_global)
 
         # self-check before anything is timed: the fused loop (one all-gather per settled iteration) must reproduce
         # the select-based loop (four all-reduces per iteration); otherwise time the latter
@@ -163,6 +268,7 @@ def main():
         def step():
             prep()
             return (freg if use_fused else sreg).run()
+    info = reg.target_info()
 
     def barrier():
         if dist is not None:
@@ -181,199 +287,177 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    T_final = out[0]
+    T_final, res_final = out[0], out[1]
 
-    # kernel-level numbers (outside the timed region): one more registration with HIP events bracketing every
-    # search kernel on the handle's own stream (params.profile_loop) -> average launch duration over the SAME
-    # 20-iteration trajectory the timed region ran; rocprofv3 --kernel-trace of this command must agree.
+    # ---- kernel-level numbers (outside the timed region) ----
     kern = {}
-    if world == 1:
-        p2 = capi.shipped_params()
-        p2.fixed_iters = ITERS
-        p2.device = local_rank
-        p2.profile_loop = 1
-        preg = capi.Registration(p2)
-        preg.set_target_device(d_tgt.data_ptr(), 3, n_tgt, d_tnrm.data_ptr(), 3)
-        preg.set_source_device(d_src.data_ptr(), 3, n_src, d_snrm.data_ptr(), 3)
-        preg.register(T_init)
-        _, pres = preg.register(T_init)
-        for idx, name in ((0, "k_match_g8"), (1, "k_iter_fused")):
-            if pres.prof_launches[idx]:
-                kern[name] = {"launches": int(pres.prof_launches[idx]), "total_ms": float(pres.prof_ms[idx]),
-                              "avg_ms": float(pres.prof_ms[idx]) / int(pres.prof_launches[idx])}
-        preg.close()
+    if not multi:
+        kern = kernel_profile(capi, ds, local_rank)
     else:
         prof = reg.profile_kernels(np.eye(4, dtype=np.float32), reps=20)
         kern["k_match_g8"] = {"launches": 20, "total_ms": 20 * prof["match_ms"], "avg_ms": prof["match_ms"]}
     dom = max(kern, key=lambda k: kern[k]["total_ms"])
     bytes_pp = KERNEL_BYTES_PER_POINT[dom]
-    achieved = n_src * bytes_pp / (kern[dom]["avg_ms"] * 1e-3) / 1e9
+    achieved = n_local * bytes_pp / (kern[dom]["avg_ms"] * 1e-3) / 1e9
+    traffic, traffic_src = pmc_traffic(workload, dom) if not multi else (None, None)
 
-    # optional: S independent registrations concurrently (replicas only, no collective) -- SURVEY 8e / config 5
-    batched = None
-    if world == 1 and args.streams > 1:
-        import threading
-        regs = []
-        for _ in range(args.streams):
-            r = capi.Registration(p)
-            r.set_target_device(d_tgt.data_ptr(), 3, n_tgt, d_tnrm.data_ptr(), 3)
-            r.set_source_device(d_src.data_ptr(), 3, n_src, d_snrm.data_ptr(), 3)
-            r.register(T_init)
-            regs.append(r)
-        per = max(2, args.steps // 2)
-        go = threading.Barrier(args.streams + 1)
-
-        def work(r):
-            go.wait()
-            for _ in range(per):
-                r.register(T_init)          # ctypes releases the GIL: the host threads really run in parallel
-            go.wait()
-
-        ths = [threading.Thread(target=work, args=(r,)) for r in regs]
-        for t in ths:
-            t.start()
-        torch.cuda.synchronize()
-        go.wait()
-        tb0 = time.perf_counter()
-        go.wait()
-        tb = time.perf_counter() - tb0
-        for t in ths:
-            t.join()
-        batched = {"streams": args.streams, "registrations": args.streams * per,
-                   "iter_per_s": args.streams * per * ITERS / tb, "ms_per_registration_amortised": 1e3 * tb / (args.streams * per)}
-        for r in regs:
-            r.close()
-
-    # secondary figure: the GICP cost (the north star's cost function; SURVEY 8d: 72 B/pt + 16 B/pt for the split
-    # kernels) on the same clouds, covariances from the analytic normals.  Never `value`.
-    gicp = None
-    if world == 1 and not force_dist and args.workload in ("c2", "tiny"):
-        pg = capi.default_params()
-        pg.cost = capi.COST_GICP
-        pg.use_trimmed = 0
-        pg.max_dist = 0.5
-        pg.fixed_iters = ITERS
-        pg.device = local_rank
-        greg = capi.Registration(pg)
-        d_tcov = torch.from_numpy(sc.tgt_cov).to(dev)
-        d_scov = torch.from_numpy(sc.src_cov[lo:hi]).to(dev)
-        torch.cuda.synchronize()
-        greg.set_target_device(d_tgt.data_ptr(), 3, n_tgt, None, 3, d_tcov.data_ptr())
-        greg.set_source_device(d_src.data_ptr(), 3, n_src, None, 3, d_scov.data_ptr())
-        for _ in range(2):
-            greg.register(T_init)
-        torch.cuda.synchronize()
-        tg0 = time.perf_counter()
-        g_steps = max(3, args.steps // 4)
-        for _ in range(g_steps):
-            Tg, gres = greg.register(T_init)
-        torch.cuda.synchronize()
-        tg = time.perf_counter() - tg0
-        gt, gr = synth.pose_error(Tg, sc.T_true)
-        gicp = {"value": ITERS * g_steps / tg, "unit": "iter/s", "ms_per_registration": 1e3 * tg / g_steps,
-                "registrations": g_steps, "bytes_per_point": 88,
-                "achieved_GBs_end_to_end": n_src * 88 * ITERS * g_steps / tg / 1e9,
-                "pose_vs_truth": {"trans_m": gt, "rot_rad": gr}, "T": Tg.tolist(),
-                "note": "GICP parity is unpinned against the reference (Open3D 0.15.1 arithmetic not in tree); "
-                        "checked against the float64 oracle in tests/test_gpu_parity.py"}
-        greg.close()
-
-    # secondary figure: the same workload with the shipped degeneracyAwareness (R8x: first-iteration localizability
-    # analysis + constrained solve) switched on.  Never `value` (SURVEY 8d defines the measured chain without it).
-    xicp = None
-    if world == 1 and not force_dist and args.workload in ("c2", "tiny"):
-        px = capi.shipped_params()
-        px.fixed_iters = ITERS
-        px.device = local_rank
-        px.use_xicp = 1
-        xreg = capi.Registration(px)
-        xreg.set_target_device(d_tgt.data_ptr(), 3, n_tgt, d_tnrm.data_ptr(), 3)
-        xreg.set_source_device(d_src.data_ptr(), 3, n_src, d_snrm.data_ptr(), 3)
-        for _ in range(2):
-            xreg.register(T_init)
-        torch.cuda.synchronize()
-        tx0 = time.perf_counter()
+    # ---- secondary objects (single GPU only; never `value`) ----
+    extras = {}
+    if not multi and not args.no_extras:
         x_steps = max(3, args.steps // 4)
-        for _ in range(x_steps):
-            Tx, xres = xreg.register(T_init)
-        torch.cuda.synchronize()
-        tx = time.perf_counter() - tx0
-        xicp = {"value": ITERS * x_steps / tx, "unit": "iter/s", "ms_per_registration": 1e3 * tx / x_steps,
-                "localizable": list(xres.localizable), "n_constraints": int(xres.n_constraints),
-                "same_pose_as_plain_chain": bool(np.array_equal(Tx, T_final))}
+        # (1) the shipped chain with its degeneracyAwareness (R8x: first-iteration localizability analysis + constrained
+        #     solve) ON -- reg_shipped_params() as it comes; the headline chain is SURVEY 8d's (without it)
+        xreg = ds.make_reg(capi, chain_params(capi, local_rank, xicp=1))
+        tx, (Tx, xres) = time_registrations(torch, xreg, T_init, x_steps)
+        extras["xicp"] = {"value": ITERS * x_steps / tx, "unit": "iter/s", "ms_per_registration": 1e3 * tx / x_steps,
+                          "workload": workload, "localizable": list(xres.localizable),
+                          "n_constraints": int(xres.n_constraints),
+                          "same_pose_as_plain_chain": bool(np.array_equal(Tx, T_final))}
         xreg.close()
+        if workload != "tiny":
+            # (2) C2 (BASELINE configs[1]): 100k -> 1M
+            n2, m2, s2 = WORKLOADS["c2"]
+            sc2 = synth.make_scene(n2, m2, seed=s2)
+            ds2 = DeviceScene(torch, dev, sc2, with_cov=True)
+            r2 = ds2.make_reg(capi, chain_params(capi, local_rank))
+            t2, (T2, res2) = time_registrations(torch, r2, T_init, args.steps)
+            e2t, e2r = synth.pose_error(T2, sc2.T_true)
+            k2 = kernel_profile(capi, ds2, local_rank)
+            extras["c2"] = {"value": ITERS * args.steps / t2, "unit": "iter/s", "ms_per_registration": 1e3 * t2 / args.steps,
+                            "workload": f"c2: {n2} -> {m2}", "pose_vs_truth": {"trans_m": e2t, "rot_rad": e2r},
+                            "kernels": k2, "target_build_ms": float(res2.target_build_ms),
+                            "source_prep_ms": float(res2.source_prep_ms)}
+            # (3) config 5 analogue on one GPU: S independent C2 registrations in flight, one HIP stream + host thread each
+            if args.streams > 1:
+                import threading
+                regs = []
+                for _ in range(args.streams):
+                    r = ds2.make_reg(capi, chain_params(capi, local_rank))
+                    r.register(T_init)
+                    regs.append(r)
+                per = max(2, args.steps // 2)
+                go = threading.Barrier(args.streams + 1)
 
-    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the number comes from
-    # the committed rocprofv3 --pmc passes of THIS command (tools/collect_profiles.sh -> profiles/r01_pmc_traffic.json;
-    # FETCH_SIZE doubled as the gfx950 guide prescribes and as the k_stream calibration in that file confirms).
-    traffic, traffic_src = None, None
-    try:
-        pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        if args.workload == "c2" and world == 1:
-            for kname, kv in pj["kernels"].items():
-                if kname.startswith(dom):
-                    traffic = kv["hbm_bytes_per_launch_corrected"]
-                    traffic_src = "profiles/r01_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, bytes per launch)"
-    except (OSError, KeyError, ValueError):
-        pass
+                def work(r):
+                    go.wait()
+                    for _ in range(per):
+                        r.register(T_init)          # ctypes releases the GIL: the host threads really run in parallel
+                    go.wait()
+
+                ths = [threading.Thread(target=work, args=(r,)) for r in regs]
+                for th in ths:
+                    th.start()
+                torch.cuda.synchronize()
+                go.wait()
+                tb0 = time.perf_counter()
+                go.wait()
+                tb = time.perf_counter() - tb0
+                for th in ths:
+                    th.join()
+                extras["batched"] = {"streams": args.streams, "registrations": args.streams * per, "workload": "c2",
+                                     "iter_per_s": args.streams * per * ITERS / tb,
+                                     "ms_per_registration_amortised": 1e3 * tb / (args.streams * per)}
+                for r in regs:
+                    r.close()
+            # (4) the GICP cost (the north star's cost function; SURVEY 8d: 72 B/pt + 16 B/pt for the split kernels) on
+            #     the C2 clouds, covariances from the analytic normals
+            pg = capi.default_params()
+            pg.cost = capi.COST_GICP
+            pg.use_trimmed = 0
+            pg.max_dist = 0.5
+            pg.fixed_iters = ITERS
+            pg.device = local_rank
+            greg = ds2.make_reg(capi, pg)
+            tg, (Tg, gres) = time_registrations(torch, greg, T_init, x_steps)
+            gt, gr = synth.pose_error(Tg, sc2.T_true)
+            extras["gicp"] = {"value": ITERS * x_steps / tg, "unit": "iter/s", "ms_per_registration": 1e3 * tg / x_steps,
+                              "workload": "c2", "bytes_per_point": 88,
+                              "achieved_GBs_end_to_end": n2 * 88 * ITERS * x_steps / tg / 1e9,
+                              "pose_vs_truth": {"trans_m": gt, "rot_rad": gr},
+                              "note": "GICP parity is unpinned against the reference (Open3D 0.15.1 arithmetic not in "
+                                      "tree); checked against the float64 oracle in tests/test_gpu_parity.py"}
+            greg.close()
+            r2.close()
+            del ds2, sc2
+            torch.cuda.empty_cache()
+            # (5) the C4 map (20M points) on ONE GPU: the whole 200k reading, and one rank's slice of an 8-way split
+            if workload != "c4":
+                n4, m4, s4 = WORKLOADS["c4"]
+                sc4 = synth.make_scene(n4, m4, seed=s4)
+                ds4 = DeviceScene(torch, dev, sc4)
+                r4 = ds4.make_reg(capi, chain_params(capi, local_rank))
+                t4, (T4, res4) = time_registrations(torch, r4, T_init, x_steps)
+                e4t, e4r = synth.pose_error(T4, sc4.T_true)
+                i4 = r4.target_info()
+                r4s = ds4.make_reg(capi, chain_params(capi, local_rank), n_src=n4 // 8)
+                t4s, _ = time_registrations(torch, r4s, T_init, x_steps)
+                extras["c4_one_gpu"] = {
+                    "value": ITERS * x_steps / t4, "unit": "iter/s", "ms_per_registration": 1e3 * t4 / x_steps,
+                    "workload": f"c4 map on one GPU: {n4} -> {m4}", "pose_vs_truth": {"trans_m": e4t, "rot_rad": e4r},
+                    "target_build_ms": float(res4.target_build_ms), "cell_size_m": i4.cell_size,
+                    "table_MB": i4.table_bytes / 1e6,
+                    "one_rank_slice": {"points": n4 // 8, "iter_per_s": ITERS * x_steps / t4s,
+                                       "ms_per_registration": 1e3 * t4s / x_steps,
+                                       "note": "what ONE of 8 ranks computes per registration, no collectives: "
+                                               "(this / value) / 8 bounds the 8-GPU strong-scaling efficiency from above"}}
+                r4.close()
+                r4s.close()
+                del ds4, sc4
+                torch.cuda.empty_cache()
 
     if rank == 0:
-        value = world * ITERS * args.steps / elapsed
+        if multi and args.mode == "weak":
+            value = world * ITERS * args.steps / elapsed     # n_src-point iteration units
+            scaling = "weak"
+        else:
+            value = ITERS * args.steps / elapsed              # whole-reading iterations
+            scaling = "strong" if multi else "weak"           # N = 1: per-GPU work is the whole job either way
         line = {
-            "metric": "ICP iterations/sec (scan-to-map, 100k-point reading units)",
+            "metric": "ICP iterations/sec (scan-to-map)",
             "value": value, "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: scan-to-map point-to-plane ICP {n_src}x{world} -> {n_tgt} points, "
-                                   f"{ITERS} iterations/registration, shipped icp.yaml chain (exact 1-NN, maxDist 0.5, "
-                                   "Trimmed 0.9, SurfaceNormal 1.57)",
-                       "n_source_per_gpu": n_src, "n_target": n_tgt, "iterations_per_step": ITERS,
-                       "parallelism": (f"point-partitioned x{world}, {loop_kind}" if (world > 1 or force_dist) else "single GPU"),
-                       "cell_size_m": info.cell_size, "n_bricks": info.n_bricks},
+            "config": {"workload": f"{workload}: scan-to-map point-to-plane ICP {n_global} -> {n_tgt} points, "
+                                   f"{ITERS} iterations/registration, icp.yaml chain (exact 1-NN, maxDist 0.5, "
+                                   "Trimmed 0.9, SurfaceNormal 1.57), degeneracyAwareness off (SURVEY 8d; with it: \"xicp\")",
+                       "n_source": n_global, "n_source_per_gpu": n_local, "n_target": n_tgt, "iterations_per_step": ITERS,
+                       "parallelism": (f"reading point-partitioned x{world} ({args.mode} scaling), map replicated, {loop_kind}"
+                                       if multi else "single GPU"),
+                       "use_xicp": 0, "cell_size_m": info.cell_size, "n_bricks": info.n_bricks,
+                       "table_MB": info.table_bytes / 1e6},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": n_src * bytes_pp,
+                         "algorithmic_bytes_per_launch": n_local * bytes_pp,
                          "kernel_ms": kern[dom]["avg_ms"], "launches": kern[dom]["launches"],
                          "bytes_per_point": bytes_pp,
-                         # measured, DESIGN.md section 6: duration = ~11 us fixed (one wave's chain of dependent round
-                         # trips) + 13.5 us per 100 k reading points; VALU -14 % changed it by -1 %
                          "limiter": "latency of dependent round trips, then Infinity-Cache/HBM fetches of the candidate "
-                                    "records an exact search has to look at (profiles/r01_search_kernel_counters.txt, "
-                                    "profiles/r01_search_kernels_vs_reading_size.txt)"},
+                                    "records an exact search has to look at (DESIGN.md section 6, profiles/)"},
             "kernels": kern,
             "roofline_iteration": {"bytes_per_point": ITER_BYTES_PER_POINT,
-                                   "achieved_GBs_end_to_end": n_src * ITER_BYTES_PER_POINT * ITERS * args.steps / elapsed / 1e9},
-            "target_build_ms": float(reg.last_result.target_build_ms) if world == 1 else None,
-            "band_stalls_last_step": int(reg.last_result.n_band_stalls) if world == 1 else None,
-            "batched": batched,
-            "gicp": gicp,
-            "xicp": xicp,
+                                   "achieved_GBs_end_to_end": n_global * ITER_BYTES_PER_POINT * ITERS * args.steps / elapsed / 1e9},
+            "target_build_ms": float(res_final.target_build_ms) if not multi else None,
+            "source_prep_ms": float(res_final.source_prep_ms) if not multi else None,
+            "band_stalls_last_step": int(res_final.n_band_stalls) if not multi else None,
         }
+        line.update(extras)
         if not args.no_cpu_baseline:
             cores = os.cpu_count() or 1
             threads = min(cores, 64)
-            cb = cpu_baseline(sc, n_src, threads)
+            cb, T_oracle = cpu_baseline(sc, threads)
             line["cpu_baseline"] = {"value": cb["omp"], "unit": "iter/s", "cores": threads, "kind": "port",
-                                    "sample": f"same {n_src}->{n_tgt} clouds and chain, {ITERS} iterations once, "
-                                              "OpenMP oracle (kd-tree build excluded)",
-                                    "value_1thread": cb["1t"]}
-            line["speedup_vs_cpu_omp"] = value / world / cb["omp"]
+                                    "cpu": cpu_model(),
+                                    "sample": f"same {n_global}->{n_tgt} clouds and chain, {ITERS} iterations once per leg, "
+                                              "OpenMP oracle (parallel search, parallel exact quantile select, parallel "
+                                              "weights and normal equations; kd-tree build excluded)",
+                                    "value_1thread": cb["1t"],
+                                    "note_1thread": "the reference's own loop is single-threaded (no OpenMP in "
+                                                    "libpointmatcher/pointmatcher): nth_element-class quantile"}
+            line["speedup_vs_cpu_omp"] = value / cb["omp"] if scaling != "weak" or world == 1 else value / world / cb["omp"]
             # final-pose parity against the oracle on the same inputs (whole reading)
-            from oracle import oracle as orc
-            To, _ = orc.icp_p2pl(sc.tgt_xyz, sc.tgt_nrm, sc.src_xyz, sc.src_nrm, max_dist=0.5, trim_ratio=0.9,
-                                 max_normal_angle=1.57, fixed_iters=ITERS, n_threads=threads)
-            dt, dr = synth.pose_error(T_final, To)
+            dt, dr = synth.pose_error(T_final, T_oracle)
             et, er = synth.pose_error(T_final, sc.T_true)
             line["pose_vs_oracle"] = {"trans_m": dt, "rot_rad": dr}
             line["pose_vs_truth"] = {"trans_m": et, "rot_rad": er}
-            if gicp is not None:
-                Tgo, gor = orc.icp_gicp(sc.tgt_xyz, sc.tgt_cov, sc.src_xyz, sc.src_cov, max_dist=0.5, fixed_iters=ITERS,
-                                        n_threads=threads)
-                gicp["cpu_oracle_iter_per_s"] = ITERS / gor.loop_seconds   # kd-tree build excluded
-                gdt, gdr = synth.pose_error(np.asarray(gicp["T"], np.float32), Tgo)
-                gicp["pose_vs_oracle"] = {"trans_m": gdt, "rot_rad": gdr}
-        if gicp is not None:
-            gicp.pop("T", None)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -87,13 +87,6 @@ typedef struct {
     float   cell_size;          /* voxel-bin edge in metres; 0 = choose from target density */
     int32_t device;             /* HIP device ordinal */
     int32_t sort_source;        /* 1: Morton-order the reading on upload (speed only; results in input order) */
-    int32_t profile_loop;       /* 1: bracket every search kernel of reg_register with HIP events (perturbs the loop slightly) */
-    int32_t match_variant;      /* 0: 8 lanes per reading point + level hints (default); 1: one lane per point; 2: 8 lanes, no hints; 3: as 0 with the level-0 histogram fused into the match kernel */
-    /* experiment switches (all 0 in production; used by the A/B scripts under tools/) */
-    int32_t debug_flags;        /* ablation bits for timing experiments: 4, 8 change results (tests only); 32 = hash instead of the dense brick directory, 64 = histogram select for every trimmed band (results unchanged) */
-    int32_t disable_halo;       /* 1: no halo-bin level 0 */
-    int32_t lanes_per_point;    /* 0 = default (8); 4 */
-    int32_t disable_fused;      /* 1: every iteration on the generic (select-based) path */
     /* degeneracyAwareness: OptimizedEqualityConstraints (icp.yaml:50-55; ICP.cpp:629-672, 2187-2444;
        PointToPlane.cpp:459-505): on the FIRST iteration the eigen-directions of the rotation / translation blocks of A
        are tested for information content (sums of |alignment| over the matched pairs above two cosine thresholds);
@@ -104,7 +97,7 @@ typedef struct {
     float   xicp_insufficient;  /* insufficientInformationThreshold (180 shipped): sum over alignment > cos(strong angle) */
     float   xicp_min_angle_deg; /* point2NormalMinimalAlignmentAngleThreshold (80 shipped) */
     float   xicp_strong_angle_deg; /* point2NormalStrongAlignmentAngleThreshold (45 shipped) */
-    int32_t reserved[1];
+    int32_t reserved[2];
 } reg_params;
 
 typedef struct {
@@ -124,28 +117,32 @@ typedef struct {
     float   T_iter_last[16];    /* final T_iter (column-major): P2PL in the centred frames, GICP == T_out */
     int32_t n_band_stalls;      /* fused path: iterations whose trimmed-band prediction failed and were re-run on the generic path */
     int32_t n_constraints;      /* use_xicp: number of non-localizable directions (0 = plain solve) */
-    float   prof_ms[4];         /* params.profile_loop: summed device time (HIP events) of [0] k_match, [1] k_iter_fused launches */
+    float   prof_ms[4];         /* loop profiling (o3dslam_reg_debug.h: profile_loop): summed device time of [0] k_match, [1] k_iter_fused launches */
     int32_t prof_launches[4];   /* ... and how many launches that was */
     /* use_xicp: [0..2] rotation eigen-directions (descending eigenvalue), [3..5] translation; 1 = localizable
        (LocalizabilityCategory, PointMatcher.h:603-607); all 1 when the analysis is off */
     int32_t localizable[6];
     double  xicp_combined[6];   /* the two information sums per direction (ICP.cpp:2128-2155) */
     double  xicp_high[6];
+    float   source_prep_ms;     /* last reg_set_source: upload + Morton order of the reading (device time, HIP events) */
+    int32_t rotation_corrected; /* 1: |1 - det R| > 1e-3 in the pre-transform -> points moved with the re-orthogonalised copy
+                                   (RigidTransformation::correctParameters, TransformationsImpl.cpp:73-76,105-166) */
 } reg_result;
 
 /* ICPChainBase::setDefault (ICP.cpp:100-113): knn 1, eps 0, maxDist inf, Trimmed 0.85,
    Counter 40, Differential 0.001/0.001/3, point-to-plane. */
 REG_API void reg_default_params(reg_params* p);
 /* open3d_slam_ros/param/icp.yaml as shipped (maxDist 0.5, Trimmed 0.9, SurfaceNormal 1.57,
-   Differential 0.001/0.008/3, Counter 30); epsilon is forced to 0 (exact search).  The degeneracyAwareness
-   thresholds are filled in (250 / 180 / 80 / 45) but use_xicp stays 0: switch it on to run R8x. */
+   Differential 0.001/0.008/3, Counter 30, degeneracyAwareness OptimizedEqualityConstraints 250 / 180 / 80 / 45 ->
+   use_xicp = 1); epsilon is forced to 0 (exact search). */
 REG_API void reg_shipped_params(reg_params* p);
 
 REG_API reg_status reg_create(const reg_params* p, reg_handle** out);
 REG_API void       reg_destroy(reg_handle* h);
 REG_API const char* reg_last_error(const reg_handle* h);
 
-/* All device work of the handle is enqueued on this hipStream_t (default: a stream the handle owns). */
+/* All device work of the handle is enqueued on this hipStream_t (default: a stream the handle owns).  Work already
+   queued on the previous stream is waited for before the switch (the handle's buffers are shared between them). */
 REG_API reg_status reg_set_stream(reg_handle* h, void* hip_stream);
 
 /* == ICP::initReference (ICP.cpp:847-898): copy, subtract centroid, build the search structure
@@ -155,9 +152,21 @@ REG_API reg_status reg_set_target(reg_handle* h, const float* xyz, int64_t xyz_s
                                   int64_t nrm_stride, const float* cov, int64_t m, int on_device);
 
 /* Reading cloud of the next reg_register / reg_prepare (ICP.cpp:952).  `nrm` is required when
-   use_surface_normal is set (else REG_MISSING_FIELD); `cov` is required for GICP. */
+   use_surface_normal is set (else REG_MISSING_FIELD); `cov` is required for GICP.
+   BUFFER LIFETIME (reg_set_target, reg_set_source and their _f64 forms): host buffers are consumed before the call
+   returns.  DEVICE buffers (on_device != 0) are read by copies / kernels enqueued on the handle's stream and the call
+   may return before they have run: keep them valid and unmodified until a later blocking call on the handle
+   (reg_register, reg_linearize, reg_get_correspondences, reg_dist_finish, ...) has returned or the stream has been
+   synchronised.  reg_set_target itself blocks until the table is built.
+   Time of the last reg_set_source (upload + Morton order) is reported as reg_result.source_prep_ms. */
 REG_API reg_status reg_set_source(reg_handle* h, const float* xyz, int64_t xyz_stride, const float* nrm,
                                   int64_t nrm_stride, const float* cov, int64_t n, int on_device);
+
+/* R11, reading side: Open3D's fp64 AoS arrays as Mapper::addRangeMeasurement holds them (points_ / normals_ n x 3
+   doubles, covariances_ n x 9 doubles or NULL), cast to fp32 on the device exactly as open3dToPointmatcher does
+   (open3d_conversions.cpp:57-118, static_cast<float> per coordinate; Mapper.cpp:288-289), then reg_set_source. */
+REG_API reg_status reg_set_source_f64(reg_handle* h, const double* xyz, const double* normals, const double* covs,
+                                      int64_t n, int on_device);
 
 /* == ICP::compute(reading, -, T_init, false) (ICP.cpp:813-844 -> 902-1349) on the reading given to
    reg_set_source: R2 reading prep, the while(iterate) loop (R3-R9) on the device, R10 composition. */

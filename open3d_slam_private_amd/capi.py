@@ -24,18 +24,28 @@ class RegError(RuntimeError):
         super().__init__(f"{STATUS_NAMES.get(status, status)}: {msg}")
 
 
+_DEBUG_FIELDS = ("profile_loop", "match_variant", "debug_flags", "disable_halo", "lanes_per_point", "disable_fused")
+
+
 class RegParams(C.Structure):
+    """include/o3dslam_reg.h reg_params.  The experiment switches of include/o3dslam_reg_debug.h (profile_loop,
+    match_variant, debug_flags, disable_halo, lanes_per_point, disable_fused) are NOT part of the C struct any more; for
+    the tests' and tools' convenience they can still be set as plain Python attributes on a RegParams object --
+    Registration() passes them on through reg_debug_configure."""
     _fields_ = [("struct_size", C.c_int32), ("cost", C.c_int32), ("knn", C.c_int32), ("max_dist", C.c_float),
                 ("epsilon", C.c_float), ("use_trimmed", C.c_int32), ("trim_ratio", C.c_float),
                 ("use_surface_normal", C.c_int32), ("max_normal_angle", C.c_float),
                 ("use_max_dist_filter", C.c_int32), ("outlier_max_dist", C.c_float), ("max_iter", C.c_int32),
                 ("min_diff_rot", C.c_float), ("min_diff_trans", C.c_float), ("smooth_len", C.c_int32),
                 ("fixed_iters", C.c_int32), ("gicp_rot_eps", C.c_float), ("gicp_trans_eps", C.c_float),
-                ("cell_size", C.c_float), ("device", C.c_int32), ("sort_source", C.c_int32),
-                ("profile_loop", C.c_int32), ("match_variant", C.c_int32), ("debug_flags", C.c_int32), ("disable_halo", C.c_int32),
-                ("lanes_per_point", C.c_int32), ("disable_fused", C.c_int32), ("use_xicp", C.c_int32),
+                ("cell_size", C.c_float), ("device", C.c_int32), ("sort_source", C.c_int32), ("use_xicp", C.c_int32),
                 ("xicp_enough", C.c_float), ("xicp_insufficient", C.c_float), ("xicp_min_angle_deg", C.c_float),
-                ("xicp_strong_angle_deg", C.c_float), ("reserved", C.c_int32 * 1)]
+                ("xicp_strong_angle_deg", C.c_float), ("reserved", C.c_int32 * 2)]
+    profile_loop = match_variant = debug_flags = disable_halo = lanes_per_point = disable_fused = 0
+
+
+class RegDebugParams(C.Structure):
+    _fields_ = [("struct_size", C.c_int32)] + [(k, C.c_int32) for k in _DEBUG_FIELDS] + [("reserved", C.c_int32)]
 
 
 class RegResult(C.Structure):
@@ -45,7 +55,8 @@ class RegResult(C.Structure):
                 ("b_last", C.c_float * 6), ("target_build_ms", C.c_float), ("loop_ms", C.c_float),
                 ("T_iter_last", C.c_float * 16), ("n_band_stalls", C.c_int32), ("n_constraints", C.c_int32),
                 ("prof_ms", C.c_float * 4), ("prof_launches", C.c_int32 * 4), ("localizable", C.c_int32 * 6),
-                ("xicp_combined", C.c_double * 6), ("xicp_high", C.c_double * 6)]
+                ("xicp_combined", C.c_double * 6), ("xicp_high", C.c_double * 6), ("source_prep_ms", C.c_float),
+                ("rotation_corrected", C.c_int32)]
 
 
 class NormalsOut(C.Structure):
@@ -80,7 +91,7 @@ EXPORTS = ["reg_default_params", "reg_shipped_params", "reg_create", "reg_destro
            "reg_dist_fused_buffers", "reg_dist_poll", "reg_estimate_normals", "reg_host_solve6_xicp",
            "reg_set_target_f64", "reg_get_target_source_indices", "reg_voxelize_within_volume", "reg_carve_indices", "reg_dist_xicp_buffers", "reg_dist_gather_buffers",
            "reg_dist_record", "reg_dist_centroid_sums", "reg_dist_prepare",
-           "reg_information_matrix"]
+           "reg_information_matrix", "reg_set_source_f64", "reg_debug_configure"]
 
 
 def lib_path() -> str:
@@ -118,6 +129,8 @@ def load_library():
     lib.reg_last_error.argtypes = [vp]
     lib.reg_last_error.restype = C.c_char_p
     lib.reg_set_stream.argtypes = [vp, vp]
+    lib.reg_debug_configure.argtypes = [vp, C.POINTER(RegDebugParams)]
+    lib.reg_set_source_f64.argtypes = [vp, vp, vp, vp, i64, C.c_int]
     lib.reg_set_target.argtypes = [vp, f32p, i64, f32p, i64, f32p, i64, C.c_int]
     lib.reg_set_source.argtypes = [vp, f32p, i64, f32p, i64, f32p, i64, C.c_int]
     lib.reg_register.argtypes = [vp, f32p, f32p, C.POINTER(RegResult)]
@@ -217,6 +230,12 @@ class Registration:
                 self._lib.reg_destroy(self._h)
                 self._h = C.c_void_p()
             raise RegError(st, msg)
+        dbg = RegDebugParams()
+        dbg.struct_size = C.sizeof(RegDebugParams)
+        for k in _DEBUG_FIELDS:
+            setattr(dbg, k, int(getattr(p, k, 0)))
+        if any(getattr(dbg, k) for k in _DEBUG_FIELDS):
+            self._check(self._lib.reg_debug_configure(self._h, C.byref(dbg)))
         self._keep = []
         self.n_source = 0
 
@@ -331,6 +350,21 @@ class Registration:
         n = xyz.shape[0] if xyz.ndim == 2 else 0
         self._check(self._lib.reg_set_source(self._h, _ptr(xyz), xyz.shape[1] if xyz.ndim == 2 else 3, _ptr(nrm),
                                              nrm.shape[1] if nrm is not None else 3, _ptr(cov), n, 0))
+        self.n_source = n
+
+    def set_source_f64(self, xyz, normals=None, covs=None):
+        """R11, reading side: Open3D's fp64 arrays (points_ / normals_ n x 3, covariances_ n x 3 x 3) cast on the device
+        as open3dToPointmatcher does (open3d_conversions.cpp:57-118)."""
+        x = np.ascontiguousarray(xyz, np.float64)
+        nr = np.ascontiguousarray(normals, np.float64) if normals is not None else None
+        cv = np.ascontiguousarray(covs, np.float64).reshape(-1, 9) if covs is not None else None
+        n = x.shape[0] if x.ndim == 2 else 0
+        self._check(self._lib.reg_set_source_f64(self._h, _ptr(x), _ptr(nr), _ptr(cv), n, 0))
+        self.n_source = n
+
+    def set_source_f64_device(self, xyz_ptr, n, nrm_ptr=None, cov_ptr=None):
+        self._check(self._lib.reg_set_source_f64(self._h, C.c_void_p(xyz_ptr), C.c_void_p(nrm_ptr) if nrm_ptr else None,
+                                                 C.c_void_p(cov_ptr) if cov_ptr else None, n, 1))
         self.n_source = n
 
     def estimate_normals(self, xyz, k=10, max_dist=np.inf, viewpoint=None, regularise=False, want_eigvals=False,

@@ -335,7 +335,7 @@ reg_status reg_dist_phase(reg_handle* h, int phase) {
             // contribution block), then the block header.  Followed by the caller's ONE all-gather.
             if (h->prm.cost != REG_COST_P2PL || h->dist_ranks <= 0) return REG_BAD_ARGUMENT;
             const FilterCfg f = make_filter_cfg(h, 0);
-            uint8_t* hint = h->prm.match_variant == 2 ? nullptr : h->i_hint.as<uint8_t>();
+            uint8_t* hint = h->dbg.match_variant == 2 ? nullptr : h->i_hint.as<uint8_t>();
             const int blocks = grid_for(h->n * 8);
             float* contrib = h->d_contrib.as<float>();
             k_iter_fused<8><<<8 * ((blocks + 7) / 8), 256, 0, h->stream>>>(

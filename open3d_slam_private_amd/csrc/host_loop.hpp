@@ -44,6 +44,12 @@ static reg_status prepare_rowmajor(reg_handle* h, const float* T_init_row, const
     std::memcpy(h->T_init, T_init_row, 64);
     const int64_t n = h->n;
     const bool p2pl = h->prm.cost == REG_COST_P2PL;
+    {
+        // R3: the rotation block of the pre-transform T0 is that of T_init bit for bit (the two centring matrices are
+        // pure translations); the kernel applies the re-orthogonalised copy to the points, this only reports it
+        float Tc[16];
+        h->rotation_corrected = (p2pl && rigid_correct(T_init_row, Tc)) ? 1 : 0;
+    }
     // centroid sums -> (device) centroid + T0; the host copy arrives later through the pinned staging buffer and is
     // only needed for the final composition (R10), so nothing here waits for the device
     HIPCHK(h, h->s_misc.reserve(256));   // allocated and cleared when the handle was created
@@ -123,7 +129,7 @@ static reg_status build_iter_state(reg_handle* h, const float* T_row, int update
     st->use_trim = (h->prm.cost == REG_COST_P2PL && h->prm.use_trimmed) ? 1 : 0;
     st->trim_ratio = h->prm.trim_ratio;
     st->band_cap = kBandCap;
-    st->debug_narrow_band = ((h->prm.debug_flags & 8) ? 1 : 0) | ((h->prm.debug_flags & 64) ? 2 : 0);   // bit 1: no direct band ranking
+    st->debug_narrow_band = ((h->dbg.debug_flags & 8) ? 1 : 0) | ((h->dbg.debug_flags & 64) ? 2 : 0);   // bit 1: no direct band ranking
     h->xicp_pending = false;
     for (int k = 0; k < 6; ++k) st->xicp_flags[k] = 1;
     if (h->prm.use_xicp && h->prm.cost == REG_COST_P2PL && update) {
@@ -188,23 +194,23 @@ static void launch_timed(reg_handle* h, int kind, K kernel, dim3 grid, dim3 bloc
 static reg_status enqueue_match(reg_handle* h, bool zero_hist = false) {
     const bool trim = h->prm.cost == REG_COST_P2PL && h->prm.use_trimmed;
     if (trim && zero_hist) HIPCHK(h, hipMemsetAsync(h->i_hist.p, 0, 3 * 2048 * 4, h->stream));
-    const bool fused_hist = h->prm.match_variant == 3;
+    const bool fused_hist = h->dbg.match_variant == 3;
     uint32_t* hist0 = (trim && fused_hist) ? h->i_hist.as<uint32_t>() : nullptr;
     uint32_t* hist2 = trim ? h->i_hist.as<uint32_t>() + 4096 : nullptr;
     const IterState* it = h->i_iter.as<IterState>();
-    if (h->prm.match_variant == 1) {
+    if (h->dbg.match_variant == 1) {
         prof_mark(h, 0, true);
         k_match<<<h->n_blocks, 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->n, it, h->grid, h->i_pos.as<int>(),
                                                     h->i_d2.as<float>(), hist0, hist2, h->shift0);
         prof_mark(h, 0, false);
     } else {
-        uint8_t* hint = h->prm.match_variant == 2 ? nullptr : h->i_hint.as<uint8_t>();
-        const int lanes = h->prm.lanes_per_point == 4 ? 4 : (h->prm.lanes_per_point == 2 ? 2 : 8);
+        uint8_t* hint = h->dbg.match_variant == 2 ? nullptr : h->i_hint.as<uint8_t>();
+        const int lanes = h->dbg.lanes_per_point == 4 ? 4 : (h->dbg.lanes_per_point == 2 ? 2 : 8);
         const int blocks = grid_for(h->n * lanes);
         const dim3 grid(8 * ((blocks + 7) / 8)), block(256);
         auto go = [&](auto kernel) {
             launch_timed(h, 0, kernel, grid, block, (const float4*)h->s_xyz.as<float4>(), h->n, it, h->grid,
-                         h->i_pos.as<int>(), h->i_d2.as<float>(), hist0, hist2, hint, h->shift0, h->prm.debug_flags, blocks);
+                         h->i_pos.as<int>(), h->i_d2.as<float>(), hist0, hist2, hint, h->shift0, h->dbg.debug_flags, blocks);
         };
         if (lanes == 4)
             go(k_match_g8<4>);
@@ -224,7 +230,7 @@ static reg_status enqueue_select(reg_handle* h) {
     const IterState* it = h->i_iter.as<IterState>();
     const int hb = std::min(h->n_blocks, 128);
     const float ratio = h->prm.trim_ratio;
-    if (h->prm.match_variant != 3)
+    if (h->dbg.match_variant != 3)
         k_hist_level0<<<hb, 256, 0, h->stream>>>(h->i_d2.as<float>(), h->n, h->shift0, hist0, it);
     k_select_level<<<hb, 256, 0, h->stream>>>(h->i_d2.as<float>(), h->n, 1, h->shift0, ratio, hist0, hist0 + 2048,
                                               nullptr, st, it);
@@ -276,7 +282,7 @@ static FilterCfg make_filter_cfg(const reg_handle* h, int trim_mode) {
     f.use_trim = trim_mode;
     f.use_normal = h->prm.use_surface_normal;
     f.use_maxdist = h->prm.use_max_dist_filter;
-    f.debug = h->prm.debug_flags;
+    f.debug = h->dbg.debug_flags;
     f.cos_max_angle = std::cos(h->prm.max_normal_angle);  // cosf in T=float (OutlierFiltersImpl.cpp:229)
     const float md = h->prm.outlier_max_dist;
     f.outlier_max_d2 = md * md;
@@ -300,8 +306,8 @@ static void launch_fused(reg_handle* h, const FilterCfg& f, float* w, uint8_t* h
 static reg_status enqueue_fused(reg_handle* h, bool want_w) {
     const FilterCfg f = make_filter_cfg(h, 0);
     float* w = want_w ? h->i_w.as<float>() : nullptr;
-    uint8_t* hint = h->prm.match_variant == 2 ? nullptr : h->i_hint.as<uint8_t>();
-    if (h->prm.lanes_per_point == 4)
+    uint8_t* hint = h->dbg.match_variant == 2 ? nullptr : h->i_hint.as<uint8_t>();
+    if (h->dbg.lanes_per_point == 4)
         launch_fused<4>(h, f, w, hint);
     else
         launch_fused<8>(h, f, w, hint);
@@ -398,6 +404,13 @@ static void fill_result(reg_handle* h, const double* sums, reg_result* res) {
     res->inlier_rmse = sums[28] > 0 ? std::sqrt(sums[30] / sums[28]) : 0.0;
     sums_to_system(sums, h->prm.cost == REG_COST_P2PL, res->H_last, res->b_last);
     res->target_build_ms = h->target_build_ms;
+    if (h->src_prep_pending && hipEventQuery(h->ev_s1) == hipSuccess) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, h->ev_s0, h->ev_s1) == hipSuccess) h->source_prep_ms = ms;
+        h->src_prep_pending = false;
+    }
+    res->source_prep_ms = h->source_prep_ms;
+    res->rotation_corrected = h->rotation_corrected;
 }
 
 extern "C" {
@@ -463,7 +476,7 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
     s = prepare_rowmajor(h, Ti, nullptr, 0, &st0);   // the state travels as an argument of the prepare kernel
     if (s != REG_OK) return s;
     rmark("prepared");
-    h->profiling = h->prm.profile_loop != 0;
+    h->profiling = h->dbg.profile_loop != 0;
     // loop_ms: HIP events only when profiling (record + synchronise cost ~20 us of host time per registration);
     // otherwise the host clock around the loop -- the loop ends when the last update kernel's mirror has arrived
     const bool event_timing = h->profiling || h->env.event_timing;
@@ -476,7 +489,7 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
     // Iterations 0..kGenericFirst-1 run on the generic (select-based) path: the trimmed limit still moves too
     // much to be predicted.  Afterwards the fused two-kernel iteration is used; if its band prediction fails the
     // device stalls the queue and the host repairs that iteration on the generic path.
-    const bool can_fuse = p2pl && h->prm.disable_fused != 1;
+    const bool can_fuse = p2pl && h->dbg.disable_fused != 1;
     const bool trimming = p2pl && h->prm.use_trimmed && h->prm.trim_ratio != 1.0f;
     const int kGenericFirst = trimming ? 2 : 1;
     const int kAhead = h->env.lookahead;

@@ -51,6 +51,51 @@ O3D_HD inline void m4_transpose(const float* A, float* B) {
     memcpy(B, R, sizeof(R));
 }
 
+// R3: RigidTransformation::checkParameters / correctParameters (TransformationsImpl.cpp:105-166), row-major 4x4.
+// |1 - det(R)| > 1e-3 in fp32 -> Tc = the re-orthogonalised copy the reference applies to the FEATURES (col1, col2
+// normalised; newCol0 = col1 x col2; newCol1 = col2 x newCol0; newCol2 = col2; translation kept).  Descriptors keep
+// the matrix as given (TransformationsImpl.cpp:83-101).  One rounding per operation; returns true when corrected.
+O3D_HD inline bool rigid_correct(const float* T, float* Tc) {
+    for (int i = 0; i < 16; ++i) Tc[i] = T[i];
+    float m0 = T[5] * T[10], m1 = T[6] * T[9];
+    const float c0 = m0 - m1;
+    m0 = T[4] * T[10]; m1 = T[6] * T[8];
+    const float c1 = m0 - m1;
+    m0 = T[4] * T[9]; m1 = T[5] * T[8];
+    const float c2 = m0 - m1;
+    float a = T[0] * c0, b = T[1] * c1;
+    float det = a - b;
+    a = T[2] * c2;
+    det = det + a;
+    const float dev = 1.0f - det;
+    if (!(fabsf(dev) > 0.001f)) return false;
+    float n1[3] = {T[1], T[5], T[9]}, n2[3] = {T[2], T[6], T[10]}, n0[3], mv[3];
+    for (int k = 0; k < 2; ++k) {   // Eigen 3.3 normalized(): z > 0 ? v / sqrt(z) : v
+        float* v = k == 0 ? n1 : n2;
+        float p = v[0] * v[0], q = v[1] * v[1];
+        float z = p + q;
+        p = v[2] * v[2];
+        z = z + p;
+        if (z > 0.f) {
+            const float s = sqrtf(z);
+            v[0] = v[0] / s; v[1] = v[1] / s; v[2] = v[2] / s;
+        }
+    }
+    float u, v;
+    u = n1[1] * n2[2]; v = n1[2] * n2[1]; n0[0] = u - v;
+    u = n1[2] * n2[0]; v = n1[0] * n2[2]; n0[1] = u - v;
+    u = n1[0] * n2[1]; v = n1[1] * n2[0]; n0[2] = u - v;
+    u = n2[1] * n0[2]; v = n2[2] * n0[1]; mv[0] = u - v;
+    u = n2[2] * n0[0]; v = n2[0] * n0[2]; mv[1] = u - v;
+    u = n2[0] * n0[1]; v = n2[1] * n0[0]; mv[2] = u - v;
+    for (int r = 0; r < 3; ++r) {
+        Tc[4 * r + 0] = n0[r];
+        Tc[4 * r + 1] = mv[r];
+        Tc[4 * r + 2] = n2[r];
+    }
+    return true;
+}
+
 O3D_HD inline bool m4_is_finite(const float* T) {
     for (int i = 0; i < 16; ++i)
         if (!(T[i] - T[i] == 0.0f)) return false;  // NaN or +-inf

@@ -41,6 +41,8 @@ struct EnvSwitches {
     int lookahead = 2;          // O3D_KAHEAD
     float settle_tol = 0.25f;   // O3D_SETTLE
     float halo_ratio = 1.5f;    // O3D_HALO_RATIO: halo-bin edge in units of the brick-table bin edge (tuning sweeps)
+    float halo_rho = 0.25f;     // O3D_HALO_RHO: exactness radius of the halo level in units of the halo-bin edge
+    float bin_occupancy = 8.f;  // O3D_BIN_OCC: points per occupied bin the automatic bin edge aims at
     void read() {
         trace = getenv("O3D_TRACE") != nullptr;
         event_timing = getenv("O3D_EVENT_TIMING") != nullptr;
@@ -50,11 +52,14 @@ struct EnvSwitches {
         if (const char* v = getenv("O3D_KAHEAD")) lookahead = std::max(1, atoi(v));
         if (const char* v = getenv("O3D_SETTLE")) settle_tol = (float)atof(v);
         if (const char* v = getenv("O3D_HALO_RATIO")) halo_ratio = std::min(4.0f, std::max(0.5f, (float)atof(v)));
+        if (const char* v = getenv("O3D_HALO_RHO")) halo_rho = std::min(1.0f, std::max(0.05f, (float)atof(v)));
+        if (const char* v = getenv("O3D_BIN_OCC")) bin_occupancy = std::min(64.0f, std::max(1.0f, (float)atof(v)));
     }
 };
 
 struct reg_handle {
     reg_params prm;
+    reg_debug_params dbg;   // experiment switches (include/o3dslam_reg_debug.h); all zero in production
     EnvSwitches env;
     std::string err;
     hipStream_t stream = nullptr;
@@ -65,6 +70,7 @@ struct reg_handle {
     DevBuf n_out, n_eig, n_cov, n_ids, n_extra, n_mom;
     DevBuf i_xicp;                 // XicpState (R8x first-iteration analysis)
     DevBuf c_in_xyz, c_in_nrm, c_in_cov, c_flags, c_offs, c_xyz, c_nrm, c_cov, c_idx;   // reg_set_target_f64
+    DevBuf r_in_xyz, r_in_nrm, r_in_cov, r_xyz, r_nrm, r_cov;                            // reg_set_source_f64
     int64_t crop_kept = 0;
     DevBuf v_fout, v_oout, v_oxyz, v_onrm, v_ocov;   // reg_voxelize_within_volume
     DevBuf v_ukeys, v_ustart;                        // reg_carve_indices
@@ -72,7 +78,10 @@ struct reg_handle {
     int64_t dist_nmax = 0;
     int dist_gather_ranks = 0;
     bool xicp_pending = false;     // the next generic iteration is followed by the analysis kernels
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_iter = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_iter = nullptr, ev_s0 = nullptr, ev_s1 = nullptr;
+    bool src_prep_pending = false;   // ev_s0 / ev_s1 bracket the last reg_set_source; folded into source_prep_ms lazily
+    float source_prep_ms = 0.f;
+    int rotation_corrected = 0;
     bool iter_copy_pending = false;
 
     // target
@@ -160,7 +169,7 @@ void reg_default_params(reg_params* p) {
     p->cell_size = 0.f;
     p->device = 0;
     p->sort_source = 1;
-    p->use_xicp = 0;
+    p->use_xicp = 0;            // ICPChainBase::setDefault has no degeneracy awareness
     p->xicp_enough = 250.f;             // icp.yaml:50-55
     p->xicp_insufficient = 180.f;
     p->xicp_min_angle_deg = 80.f;
@@ -179,6 +188,7 @@ void reg_shipped_params(reg_params* p) {
     p->min_diff_rot = 0.001f;
     p->min_diff_trans = 0.008f;
     p->smooth_len = 3;
+    p->use_xicp = 1;            // degeneracyAwareness: OptimizedEqualityConstraints (icp.yaml:50-55)
 }
 
 reg_status reg_create(const reg_params* p, reg_handle** out) {
@@ -193,6 +203,7 @@ reg_status reg_create(const reg_params* p, reg_handle** out) {
     if (p->use_xicp && p->cost != REG_COST_P2PL) return REG_BAD_ARGUMENT;   // the analysis expects point-to-plane (ICP.cpp:1118)
     reg_handle* h = new reg_handle();
     h->prm = *p;
+    std::memset(&h->dbg, 0, sizeof(h->dbg));
     h->env.read();
     std::memset(&h->info, 0, sizeof(h->info));
     std::memset(&h->grid, 0, sizeof(h->grid));
@@ -208,6 +219,8 @@ reg_status reg_create(const reg_params* p, reg_handle** out) {
     (void)hipEventCreate(&h->ev0);
     (void)hipEventCreate(&h->ev1);
     (void)hipEventCreateWithFlags(&h->ev_iter, hipEventDisableTiming);
+    (void)hipEventCreate(&h->ev_s0);
+    (void)hipEventCreate(&h->ev_s1);
     if (hipHostMalloc((void**)&h->h_mirror, sizeof(HostMirror), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&h->d_mirror, h->h_mirror, 0) != hipSuccess ||
         hipHostMalloc((void**)&h->h_iter, sizeof(IterState), hipHostMallocDefault) != hipSuccess ||
@@ -229,7 +242,7 @@ void reg_destroy(reg_handle* h) {
     if (h->normals_ws) reg_destroy(h->normals_ws);
     h->n_out.release();
     h->i_xicp.release();
-    for (DevBuf* b : {&h->c_in_xyz, &h->c_in_nrm, &h->c_in_cov, &h->c_flags, &h->c_offs, &h->c_xyz, &h->c_nrm, &h->c_cov, &h->c_idx, &h->v_fout, &h->v_oout, &h->v_oxyz, &h->v_onrm, &h->v_ocov, &h->v_ukeys, &h->v_ustart, &h->d_d2all}) b->release();
+    for (DevBuf* b : {&h->c_in_xyz, &h->c_in_nrm, &h->c_in_cov, &h->c_flags, &h->c_offs, &h->c_xyz, &h->c_nrm, &h->c_cov, &h->c_idx, &h->v_fout, &h->v_oout, &h->v_oxyz, &h->v_onrm, &h->v_ocov, &h->v_ukeys, &h->v_ustart, &h->d_d2all, &h->r_in_xyz, &h->r_in_nrm, &h->r_in_cov, &h->r_xyz, &h->r_nrm, &h->r_cov}) b->release();
     h->n_eig.release();
     h->n_cov.release();
     h->n_ids.release();
@@ -247,17 +260,33 @@ void reg_destroy(reg_handle* h) {
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_iter) (void)hipEventDestroy(h->ev_iter);
+    if (h->ev_s0) (void)hipEventDestroy(h->ev_s0);
+    if (h->ev_s1) (void)hipEventDestroy(h->ev_s1);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
 
 const char* reg_last_error(const reg_handle* h) { return h ? h->err.c_str() : "null handle"; }
 
+reg_status reg_debug_configure(reg_handle* h, const reg_debug_params* d) {
+    if (!h || !d || d->struct_size != (int32_t)sizeof(reg_debug_params)) return REG_BAD_ARGUMENT;
+    h->dbg = *d;
+    return REG_OK;
+}
+
 reg_status reg_set_stream(reg_handle* h, void* hip_stream) {
     if (!h) return REG_BAD_ARGUMENT;
+    if (!h->device_ok) return REG_DEVICE_ERROR;
+    if ((hipStream_t)hip_stream == h->stream) return REG_OK;
+    HIPCHK(h, hipSetDevice(h->prm.device));
+    // Work already queued on the old stream (the D2D upload and Morton sort of reg_set_source, a table build, an
+    // iteration) must have finished before anything is enqueued on the new one: the buffers are shared and there is no
+    // other ordering between the two streams.  Switching streams is rare; a full wait is the simple, safe form.
+    if (h->stream) HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     h->stream = (hipStream_t)hip_stream;
     h->own_stream = false;
+    h->iter_copy_pending = false;   // the staging copy has completed with the old stream
     return REG_OK;
 }
 
@@ -366,7 +395,7 @@ static reg_status build_grid(reg_handle* h, float c, const float bmin[3], const 
     const int bdx = (int)std::ceil(dims[0] / kBrickDim), bdy = (int)std::ceil(dims[1] / kBrickDim),
               bdz = (int)std::ceil(dims[2] / kBrickDim);
     const size_t n_dir = (size_t)bdx * bdy * bdz;
-    const bool use_dir = n_dir <= ((size_t)64 << 20) && !(h->prm.debug_flags & 32);
+    const bool use_dir = n_dir <= ((size_t)64 << 20) && !(h->dbg.debug_flags & 32);
     if (use_dir) {
         HIPCHK(h, h->t_dir.reserve(n_dir * 4));
         HIPCHK(h, hipMemsetAsync(h->t_dir.p, 0xff, n_dir * 4, h->stream));
@@ -424,17 +453,17 @@ static reg_status build_halo(reg_handle* h, float c, const float bmin[3], const 
     Grid& g = h->grid;
     g.use_halo = 0;
     g.level_after_halo = 0;
-    if (h->prm.disable_halo == 1) return REG_OK;  // A/B experiments
+    if (h->dbg.disable_halo == 1) return REG_OK;  // A/B experiments
     const float ch = h->env.halo_ratio * c;
     const float abs_margin = 4e-7f * (1.0f + max_abs);
-    const float rho_h = 0.25f * ch * (1.0f - 4e-3f) - 2.f * abs_margin;
+    const float rho_h = h->env.halo_rho * ch * (1.0f - 4e-3f) - 2.f * abs_margin;
     if (!(rho_h > 0.f)) return REG_OK;
     const float r_ins = rho_h + 1e-3f * rho_h + abs_margin;
     const float inv = 1.0f / ch;
     double dims[3];
     for (int k = 0; k < 3; ++k) dims[k] = std::floor((double)(bmax[k] - bmin[k]) * inv) + 1.0;
     const double nb = dims[0] * dims[1] * dims[2];
-    if (nb > 48e6) return REG_OK;
+    if (nb > 512e6) return REG_OK;   // 2 GB of bin starts: nothing against 288 GB of HBM (a 20 M-point map needs ~30 M bins)
     const size_t nbins = (size_t)nb;
     HaloCfg hc;
     hc.ox = bmin[0];
@@ -487,10 +516,23 @@ static reg_status build_halo(reg_handle* h, float c, const float bmin[3], const 
 
 extern "C" {
 
+static reg_status set_target_impl(reg_handle* h, const float* xyz, int64_t xyz_stride, const float* nrm, int64_t nrm_stride,
+                                  const float* cov, int64_t m, int on_device);
+
 reg_status reg_set_target(reg_handle* h, const float* xyz, int64_t xyz_stride, const float* nrm, int64_t nrm_stride,
                           const float* cov, int64_t m, int on_device) {
     if (!h) return REG_BAD_ARGUMENT;
     if (!h->device_ok) return REG_DEVICE_ERROR;
+    // The reference re-derives everything in compute() after initReference(): a reading prepared against the previous
+    // reference (centred on the old c_ref, pre-transformed with the old T0) must not be used with the new one.
+    h->prepared = false;
+    const reg_status s = set_target_impl(h, xyz, xyz_stride, nrm, nrm_stride, cov, m, on_device);
+    if (s != REG_OK) h->m = 0;   // a failed build leaves NO reference (tables, origin and dims may be half-updated)
+    return s;
+}
+
+static reg_status set_target_impl(reg_handle* h, const float* xyz, int64_t xyz_stride, const float* nrm, int64_t nrm_stride,
+                                  const float* cov, int64_t m, int on_device) {
     h->m = 0;
     h->crop_kept = 0;
     h->have_match = false;
@@ -572,16 +614,17 @@ reg_status reg_set_target(reg_handle* h, const float* xyz, int64_t xyz_stride, c
     } else {
         const float ext = std::max(bmax[0] - bmin[0], std::max(bmax[1] - bmin[1], bmax[2] - bmin[2]));
         // start from the edge that would give 8 points per bin if the cloud were a single ext x ext sheet
-        cs = std::max(ext * std::sqrt(8.0f / (float)m), 1e-4f * std::max(ext, 1e-3f));
+        const float occ = h->env.bin_occupancy;
+        cs = std::max(ext * std::sqrt(occ / (float)m), 1e-4f * std::max(ext, 1e-3f));
         const float cs_min = std::max(ext / (float)(1u << 20), 1e-6f);
         cs = std::max(cs, cs_min);
         for (int pass = 0; pass < 3; ++pass) {
             reg_status s = build_grid(h, cs, bmin, bmax, &occupied);
             if (s != REG_OK) return s;
             const float per = (float)m / (float)std::max(1u, occupied);
-            if (per <= 12.0f && per >= 5.0f) break;
+            if (per <= 1.5f * occ && per >= 0.625f * occ) break;
             if (pass == 2) break;
-            float next = cs * std::sqrt(8.0f / per);
+            float next = cs * std::sqrt(occ / per);
             next = std::max(next, cs_min);
             if (std::fabs(next - cs) < 0.05f * cs) break;
             cs = next;
@@ -618,8 +661,9 @@ reg_status reg_set_target_f64(reg_handle* h, const double* xyz, const double* no
     if (!h->device_ok) return REG_DEVICE_ERROR;
     if (n_kept) *n_kept = 0;
     h->crop_kept = 0;
+    h->m = 0;            // whatever happens below, the previous reference is gone (its staging buffers are reused)
+    h->prepared = false;
     if (m <= 0) {
-        h->m = 0;
         h->err = "The reference point cloud is empty";
         return REG_EMPTY_TARGET;
     }
@@ -991,9 +1035,10 @@ reg_status reg_estimate_normals(reg_handle* h, const float* xyz, int64_t xyz_str
     if (!h->normals_ws) {
         reg_params p = h->prm;
         p.cost = REG_COST_GICP;   // no centring: neighbourhoods are formed in the input frame
-        p.disable_halo = 1;
+        p.use_xicp = 0;
         reg_handle* w = nullptr;
         const reg_status cs = reg_create(&p, &w);
+        if (w) w->dbg.disable_halo = 1;   // the k-NN search uses the brick table only
         if (cs != REG_OK) {
             h->err = std::string("reg_estimate_normals: workspace: ") + reg_last_error(w);
             reg_destroy(w);
@@ -1100,6 +1145,7 @@ reg_status reg_set_source(reg_handle* h, const float* xyz, int64_t xyz_stride, c
         return REG_MISSING_FIELD;
     }
     HIPCHK(h, hipSetDevice(h->prm.device));
+    HIPCHK(h, hipEventRecord(h->ev_s0, h->stream));
     // packed private copies (the reference deep-copies the reading, ICP.cpp:952)
     reg_status s = upload(h, h->s_raw, xyz, (size_t)n * xyz_stride * 4, on_device);
     if (s != REG_OK) return s;
@@ -1151,7 +1197,52 @@ reg_status reg_set_source(reg_handle* h, const float* xyz, int64_t xyz_stride, c
                                             h->stream));
         h->perm = h->s_perm2.as<uint32_t>();
     }
+    HIPCHK(h, hipEventRecord(h->ev_s1, h->stream));
+    h->src_prep_pending = true;
     return REG_OK;
+}
+
+// R11, reading side: open3dToPointmatcher (open3d_conversions.cpp:57-118) converts every scan from Open3D's fp64 AoS
+// (std::vector<Eigen::Vector3d> points_ / normals_, Matrix3d covariances_) to fp32 before icp_.compute
+// (Mapper.cpp:288-289).  The cast runs on the device (round-to-nearest, as static_cast<float>), then reg_set_source.
+reg_status reg_set_source_f64(reg_handle* h, const double* xyz, const double* normals, const double* covs, int64_t n,
+                              int on_device) {
+    if (!h) return REG_BAD_ARGUMENT;
+    if (!h->device_ok) return REG_DEVICE_ERROR;
+    h->n = 0;
+    h->prepared = false;
+    h->have_match = false;
+    if (n <= 0) {
+        h->err = "The reading point cloud is empty.";
+        return REG_EMPTY_SOURCE;
+    }
+    if (!xyz || n > 0x7fffffffLL) return REG_BAD_ARGUMENT;
+    HIPCHK(h, hipSetDevice(h->prm.device));
+    const double *d_xyz = xyz, *d_nrm = normals, *d_cov = covs;
+    if (!on_device) {
+        HIPCHK(h, h->r_in_xyz.reserve((size_t)n * 24));
+        HIPCHK(h, hipMemcpyAsync(h->r_in_xyz.p, xyz, (size_t)n * 24, hipMemcpyHostToDevice, h->stream));
+        d_xyz = h->r_in_xyz.as<double>();
+        if (normals) {
+            HIPCHK(h, h->r_in_nrm.reserve((size_t)n * 24));
+            HIPCHK(h, hipMemcpyAsync(h->r_in_nrm.p, normals, (size_t)n * 24, hipMemcpyHostToDevice, h->stream));
+            d_nrm = h->r_in_nrm.as<double>();
+        }
+        if (covs) {
+            HIPCHK(h, h->r_in_cov.reserve((size_t)n * 72));
+            HIPCHK(h, hipMemcpyAsync(h->r_in_cov.p, covs, (size_t)n * 72, hipMemcpyHostToDevice, h->stream));
+            d_cov = h->r_in_cov.as<double>();
+        }
+    }
+    HIPCHK(h, h->r_xyz.reserve((size_t)n * 12));
+    if (d_nrm) HIPCHK(h, h->r_nrm.reserve((size_t)n * 12));
+    if (d_cov) HIPCHK(h, h->r_cov.reserve((size_t)n * 24));
+    k_cast_cloud_f64<<<grid_for(n), 256, 0, h->stream>>>(d_xyz, d_nrm, d_cov, n, h->r_xyz.as<float>(),
+                                                          d_nrm ? h->r_nrm.as<float>() : nullptr,
+                                                          d_cov ? h->r_cov.as<float>() : nullptr);
+    HIPCHK(h, hipGetLastError());
+    return reg_set_source(h, h->r_xyz.as<float>(), 3, d_nrm ? h->r_nrm.as<float>() : nullptr, 3,
+                          d_cov ? h->r_cov.as<float>() : nullptr, n, 1);
 }
 
 }  // extern "C"

@@ -59,6 +59,25 @@ __global__ void k_crop_gather(const double* __restrict__ xyz, const double* __re
     oidx[o] = (int32_t)i;
 }
 
+// R11, reading side (open3d_conversions.cpp:57-118): fp64 AoS -> fp32, same order, nothing dropped
+__global__ void k_cast_cloud_f64(const double* __restrict__ xyz, const double* __restrict__ nrm, const double* __restrict__ cov,
+                                 int64_t n, float* __restrict__ oxyz, float* __restrict__ onrm, float* __restrict__ ocov) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int k = 0; k < 3; ++k) oxyz[3 * i + k] = (float)xyz[3 * i + k];
+    if (nrm)
+        for (int k = 0; k < 3; ++k) onrm[3 * i + k] = (float)nrm[3 * i + k];
+    if (cov) {
+        const double* c = cov + 9 * i;   // Matrix3d, symmetric: xx xy xz / . yy yz / . . zz
+        ocov[6 * i + 0] = (float)c[0];
+        ocov[6 * i + 1] = (float)c[1];
+        ocov[6 * i + 2] = (float)c[2];
+        ocov[6 * i + 3] = (float)c[4];
+        ocov[6 * i + 4] = (float)c[5];
+        ocov[6 * i + 5] = (float)c[8];
+    }
+}
+
 // ---- voxelizeWithinCroppingVolume (helpers.cpp:117-192) ----
 constexpr int kVoxBits = 21;                       // voxel index bits per axis in the sort key (offset binary)
 constexpr long long kVoxOff = 1ll << (kVoxBits - 1);

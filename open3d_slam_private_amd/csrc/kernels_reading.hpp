@@ -115,9 +115,16 @@ __global__ void k_prepare_source(const float* __restrict__ xyz, int64_t stride, 
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     hint[i] = 0;
-    Xf T0;
+    // R3 (TransformationsImpl.cpp:73-76): a pre-transform whose rotation block is off by |1 - det| > 1e-3 moves the POINTS
+    // with the re-orthogonalised copy; the normals and the composed result keep the matrix as given
+    float T0c[16];
+    rigid_correct(T0f, T0c);
+    Xf T0, T0p;
 #pragma unroll
-    for (int k = 0; k < 12; ++k) T0.m[k] = T0f[k];
+    for (int k = 0; k < 12; ++k) {
+        T0.m[k] = T0f[k];
+        T0p.m[k] = T0c[k];
+    }
     const float cx = c[0], cy = c[1], cz = c[2];
     const int64_t src = perm ? (int64_t)perm[i] : i;
     const float* p = xyz + src * stride;
@@ -126,7 +133,7 @@ __global__ void k_prepare_source(const float* __restrict__ xyz, int64_t stride, 
         x = x - cx;
         y = y - cy;
         z = z - cz;
-        const float3 q = xf_point(T0, x, y, z);
+        const float3 q = xf_point(T0p, x, y, z);
         x = q.x; y = q.y; z = q.z;
     }
     out_xyz[i] = make_float4(x, y, z, 1.f);

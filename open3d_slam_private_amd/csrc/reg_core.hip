@@ -2,6 +2,7 @@
 // gfx950 only.  The product never falls back to a CPU path: every entry point that needs the
 // device returns REG_DEVICE_ERROR when HIP fails.
 #include "../../include/o3dslam_reg.h"
+#include "../../include/o3dslam_reg_debug.h"
 #include "host_math.hpp"
 #include "reg_kernels.hpp"
 

@@ -97,46 +97,132 @@ def make_primitives(rng):
     return prims
 
 
-def _sample(prims, n, rng, radius=None):
-    """n points uniformly by area (optionally only within `radius` of the origin, by rejection)."""
-    areas = np.array([p.area for p in prims])
-    prob = areas / areas.sum()
-    pts_l, nrm_l = [], []
-    have = 0
-    while have < n:
-        want = int((n - have) * (1.3 if radius is None else 3.0)) + 64
-        counts = rng.multinomial(want, prob)
-        P = np.empty((want, 3))
-        Nn = np.zeros((want, 3))
-        o = 0
-        for prim, cnt in zip(prims, counts):
-            if cnt == 0:
-                continue
-            sl = slice(o, o + cnt)
-            if isinstance(prim, _Rect):
-                P[sl] = prim.c
-                P[sl, prim.u] += rng.uniform(-prim.hu, prim.hu, cnt)
-                P[sl, prim.v] += rng.uniform(-prim.hv, prim.hv, cnt)
-                Nn[sl, prim.k] = prim.sgn
+class _PrimTable:
+    """Vectorised view of the primitives: per-primitive parameter arrays, so that a batch of (primitive, u, v)
+    triples turns into points and analytic normals without a Python loop over primitives."""
+
+    def __init__(self, prims):
+        n = len(prims)
+        self.is_cyl = np.zeros(n, bool)
+        self.c = np.zeros((n, 3))          # rect: centre; cyl: (cx, cy, z0)
+        self.ax = np.zeros((n, 3), np.int64)   # rect: (u axis, v axis, normal axis)
+        self.h = np.zeros((n, 2))          # rect: half extents (hu, hv); cyl: (r, z1 - z0)
+        self.sgn = np.zeros(n)
+        self.area = np.array([p.area for p in prims])
+        # extent of the (u, v) parameter rectangle in metres: rect 2hu x 2hv, cylinder circumference x height
+        self.len_u = np.zeros(n)
+        self.len_v = np.zeros(n)
+        for i, p in enumerate(prims):
+            if isinstance(p, _Rect):
+                self.c[i] = p.c
+                self.ax[i] = (p.u, p.v, p.k)
+                self.h[i] = (p.hu, p.hv)
+                self.sgn[i] = p.sgn
+                self.len_u[i], self.len_v[i] = 2 * p.hu, 2 * p.hv
             else:
-                th = rng.uniform(0, 2 * math.pi, cnt)
-                P[sl, 0] = prim.cx + prim.r * np.cos(th)
-                P[sl, 1] = prim.cy + prim.r * np.sin(th)
-                P[sl, 2] = rng.uniform(prim.z0, prim.z1, cnt)
-                Nn[sl, 0] = np.cos(th)
-                Nn[sl, 1] = np.sin(th)
-            o += cnt
-        perm = rng.permutation(want)
-        P, Nn = P[perm], Nn[perm]
+                self.is_cyl[i] = True
+                self.c[i] = (p.cx, p.cy, p.z0)
+                self.h[i] = (p.r, p.z1 - p.z0)
+                self.len_u[i], self.len_v[i] = 2 * math.pi * p.r, p.z1 - p.z0
+
+    def points(self, prim, fu, fv):
+        """prim: primitive index per point; fu, fv in [0, 1): position in the primitive's parameter rectangle."""
+        n = prim.shape[0]
+        P = np.empty((n, 3))
+        Nn = np.zeros((n, 3))
+        cyl = self.is_cyl[prim]
+        r = ~cyl
+        if r.any():
+            pr = prim[r]
+            Pr = self.c[pr].copy()
+            rows = np.arange(pr.shape[0])
+            Pr[rows, self.ax[pr, 0]] += (2.0 * fu[r] - 1.0) * self.h[pr, 0]
+            Pr[rows, self.ax[pr, 1]] += (2.0 * fv[r] - 1.0) * self.h[pr, 1]
+            P[r] = Pr
+            Nr = np.zeros((pr.shape[0], 3))
+            Nr[rows, self.ax[pr, 2]] = self.sgn[pr]
+            Nn[r] = Nr
+        if cyl.any():
+            pc = prim[cyl]
+            th = 2.0 * math.pi * fu[cyl]
+            ct, st = np.cos(th), np.sin(th)
+            P[cyl, 0] = self.c[pc, 0] + self.h[pc, 0] * ct
+            P[cyl, 1] = self.c[pc, 1] + self.h[pc, 0] * st
+            P[cyl, 2] = self.c[pc, 2] + fv[cyl] * self.h[pc, 1]
+            Nn[cyl, 0] = ct
+            Nn[cyl, 1] = st
+        return P, Nn
+
+
+_CHUNK = 1 << 20
+
+
+def _rng(seed, stream, k):
+    return np.random.Generator(np.random.PCG64(np.random.SeedSequence([int(seed), int(stream), int(k)])))
+
+
+def _run_chunks(fn, n_chunks):
+    """Chunks are independent (one PCG64 stream each), so the result does not depend on the thread count."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    workers = max(1, min(n_chunks, int(os.environ.get("O3D_SYNTH_THREADS", min(16, os.cpu_count() or 1)))))
+    if workers == 1 or n_chunks == 1:
+        return [fn(k) for k in range(n_chunks)]
+    with ThreadPoolExecutor(workers) as ex:
+        return list(ex.map(fn, range(n_chunks)))
+
+
+def _sample_stratified(tab, n, seed, noise):
+    """`n` points, one per cell of a regular (u, v) lattice over every primitive (jittered inside the cell): the
+    surface density of a voxel-deduplicated map (param_velodyne_puck16.lua:50) without oversampling and sorting.
+    The lattice edge is chosen so that there are ~8 % more cells than points; a random subset of exactly n is kept."""
+    total_area = float(tab.area.sum())
+    v = math.sqrt(total_area / (n * 1.08))
+    while True:
+        nu = np.maximum(np.ceil(tab.len_u / v), 1).astype(np.int64)
+        nv = np.maximum(np.ceil(tab.len_v / v), 1).astype(np.int64)
+        cum = np.concatenate([[0], np.cumsum(nu * nv)])
+        if cum[-1] >= n:
+            break
+        v *= 0.98
+    K = int(cum[-1])
+    sel = _rng(seed, 11, 0).permutation(K)[:n]          # which cells carry a point, in random order
+    n_chunks = (n + _CHUNK - 1) // _CHUNK
+
+    def chunk(k):
+        idx = sel[k * _CHUNK:(k + 1) * _CHUNK]
+        prim = np.searchsorted(cum, idx, side="right") - 1
+        local = idx - cum[prim]
+        iu, iv = local // nv[prim], local % nv[prim]
+        g = _rng(seed, 12, k)
+        fu = (iu + g.random(idx.shape[0])) / nu[prim]
+        fv = (iv + g.random(idx.shape[0])) / nv[prim]
+        P, Nn = tab.points(prim, fu, fv)
+        P += g.normal(0.0, noise, P.shape)
+        return P.astype(np.float32), _orient_to_sensor(P, Nn).astype(np.float32)
+
+    parts = _run_chunks(chunk, n_chunks)
+    return np.concatenate([p for p, _ in parts]), np.concatenate([q for _, q in parts])
+
+
+def _sample_uniform(tab, n, seed, noise, radius=None, stream=21):
+    """`n` points uniformly by area (optionally only within `radius` of the origin, by rejection)."""
+    cumprob = np.cumsum(tab.area / tab.area.sum())
+    pts, nrms, have, k = [], [], 0, 0
+    while have < n:
+        want = min(_CHUNK, int((n - have) * (1.15 if radius is None else 2.2)) + 64)
+        g = _rng(seed, stream, k)
+        k += 1
+        prim = np.minimum(np.searchsorted(cumprob, g.random(want), side="right"), cumprob.shape[0] - 1)
+        P, Nn = tab.points(prim, g.random(want), g.random(want))
         if radius is not None:
-            keep = np.linalg.norm(P, axis=1) <= radius
+            keep = np.einsum("ij,ij->i", P, P) <= radius * radius
             P, Nn = P[keep], Nn[keep]
-        pts_l.append(P)
-        nrm_l.append(Nn)
+        P = P + g.normal(0.0, noise, P.shape)
+        pts.append(P)
+        nrms.append(_orient_to_sensor(P, Nn))
         have += P.shape[0]
-    P = np.concatenate(pts_l)[:n]
-    Nn = np.concatenate(nrm_l)[:n]
-    return P, Nn
+    return np.concatenate(pts)[:n], np.concatenate(nrms)[:n]
 
 
 def _orient_to_sensor(P, Nn):
@@ -173,36 +259,19 @@ class Scene:
 
 def make_scene(n_src: int, n_tgt: int, seed: int = 1234, noise: float = 0.01, radius: float = 25.0,
                dedup: bool = True) -> Scene:
+    """Deterministic in (n_src, n_tgt, seed, noise, radius, dedup); independent of the thread count."""
     rng = np.random.Generator(np.random.PCG64(seed))
-    prims = make_primitives(rng)
-    total_area = float(sum(p.area for p in prims))
+    tab = _PrimTable(make_primitives(rng))
     if dedup and n_tgt >= 1000:
-        # roughly one point per voxel, like a voxelised map (param_velodyne_puck16.lua:50)
-        v = math.sqrt(total_area / (n_tgt * 1.15))
-        raw, rawn = _sample(prims, int(3.0 * n_tgt), rng)
-        key = np.floor(raw / v).astype(np.int64)
-        h = (key[:, 0] * 73856093) ^ (key[:, 1] * 19349663) ^ (key[:, 2] * 83492791)
-        _, first = np.unique(h, return_index=True)
-        first.sort()
-        if first.shape[0] >= n_tgt:
-            sel = first[rng.permutation(first.shape[0])[:n_tgt]]
-        else:
-            rest = np.setdiff1d(np.arange(raw.shape[0]), first, assume_unique=False)
-            sel = np.concatenate([first, rest[: n_tgt - first.shape[0]]])
-        T, Tn = raw[sel], rawn[sel]
+        T, Tn = _sample_stratified(tab, n_tgt, seed, noise)    # roughly one point per voxel, like a voxelised map
     else:
-        T, Tn = _sample(prims, n_tgt, rng)
-    T = T + rng.normal(0.0, noise, T.shape)
-    Tn = _orient_to_sensor(T, Tn)
-    rng2 = np.random.Generator(np.random.PCG64(seed + 1))
-    S, Sn = _sample(prims, n_src, rng2, radius=radius)
-    S = S + rng2.normal(0.0, noise, S.shape)
-    Sn = _orient_to_sensor(S, Sn)
+        T, Tn = _sample_uniform(tab, n_tgt, seed, noise, stream=22)
+    S, Sn = _sample_uniform(tab, n_src, seed + 1, noise, radius=radius)
     Tt = true_transform()
     Ti = np.linalg.inv(Tt)
     S = S @ Ti[:3, :3].T + Ti[:3, 3]
     Sn = Sn @ Ti[:3, :3].T
-    return Scene(T.astype(np.float32), Tn.astype(np.float32), S.astype(np.float32), Sn.astype(np.float32), Tt)
+    return Scene(np.asarray(T, np.float32), np.asarray(Tn, np.float32), S.astype(np.float32), Sn.astype(np.float32), Tt)
 
 
 def pose_error(T, T_ref):

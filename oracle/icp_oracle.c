@@ -301,14 +301,105 @@ ORC_API void orc_knn_brute(const float* tgt_xyz, int64_t tgt_stride, int64_t m, 
 /* R5: outlier filters                                                        */
 /* ------------------------------------------------------------------------- */
 
-static int cmp_float(const void* a, const void* b) {
-    float x = *(const float*)a, y = *(const float*)b;
-    return (x > y) - (x < y);
+/* k-th smallest of v[0..n) in place (Hoare quickselect with median-of-three pivots): the nth_element-class
+   selection the reference uses (Matches.cpp:83 std::nth_element), O(n) expected instead of a full sort. */
+static float select_kth(float* v, int64_t n, int64_t k) {
+    int64_t lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int64_t mid = lo + (hi - lo) / 2;
+        float a = v[lo], b = v[mid], c = v[hi];
+        const float pivot = (a < b) ? ((b < c) ? b : (a < c ? c : a)) : ((a < c) ? a : (b < c ? c : b));
+        int64_t i = lo, j = hi;
+        while (i <= j) {
+            while (v[i] < pivot) ++i;
+            while (v[j] > pivot) --j;
+            if (i <= j) {
+                const float t = v[i];
+                v[i] = v[j];
+                v[j] = t;
+                ++i;
+                --j;
+            }
+        }
+        if (k <= j)
+            hi = j;
+        else if (k >= i)
+            lo = i;
+        else
+            return v[k];
+    }
+    return v[k];
+}
+
+/* NC6: index of the quantile among k finite values: `values.size() * quantile` evaluated in T=float, truncated
+   (Matches.cpp:82-86); quantile == 1 -> the maximum */
+static int64_t trim_index(int64_t k, float ratio) {
+    if (ratio == 1.0f) return k - 1;
+    float pos = (float)k * ratio;
+    int64_t idx = (int64_t)pos;
+    if (idx >= k) idx = k - 1;
+    if (idx < 0) idx = 0;
+    return idx;
+}
+
+/* Multi-threaded exact selection for the OpenMP leg of the CPU baseline: the squared distances are >= 0, so their
+   fp32 bit patterns order like the values; three histogram passes (11 + 11 + 10 bits, per-thread bins) find the
+   idx-th smallest finite value exactly.  Same result as the serial selection by construction (tests compare them). */
+static float select_kth_radix_mt(const float* d2, int64_t n, int64_t idx, int n_threads) {
+    uint32_t prefix = 0, mask = 0;
+    int64_t rank = idx;
+    static const int shift[3] = {21, 10, 0};
+    static const int bins[3] = {2048, 2048, 1024};
+    for (int level = 0; level < 3; ++level) {
+        const int nb = bins[level], sh = shift[level];
+        int64_t* hist = (int64_t*)calloc((size_t)nb, sizeof(int64_t));
+#ifdef _OPENMP
+#pragma omp parallel num_threads(n_threads > 0 ? n_threads : 1)
+#endif
+        {
+            int64_t* loc = (int64_t*)calloc((size_t)nb, sizeof(int64_t));
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+            for (int64_t i = 0; i < n; ++i) {
+                uint32_t u;
+                memcpy(&u, d2 + i, 4);
+                if (u == 0x7f800000u || (u & mask) != prefix) continue;
+                ++loc[(u >> sh) & (uint32_t)(nb - 1)];
+            }
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+            for (int b = 0; b < nb; ++b) hist[b] += loc[b];
+            free(loc);
+        }
+        int b = 0;
+        while (b < nb - 1 && rank >= hist[b]) rank -= hist[b++];
+        prefix |= (uint32_t)b << sh;
+        mask |= (uint32_t)(nb - 1) << sh;
+        free(hist);
+    }
+    float out;
+    memcpy(&out, &prefix, 4);
+    (void)n_threads;
+    return out;
 }
 
 /* Matches::getDistsQuantile (Matches.cpp:60-87).  Returns 0 and sets *limit, or -1 when
-   no finite distance exists (reference throws ConvergenceError). */
-ORC_API int orc_trim_limit(const float* d2, int64_t n, float ratio, float* limit, int64_t* n_finite) {
+   no finite distance exists (reference throws ConvergenceError).  n_threads <= 1: copy of the finite values +
+   nth_element-class selection, as the reference does; n_threads > 1: parallel exact radix selection. */
+ORC_API int orc_trim_limit_mt(const float* d2, int64_t n, float ratio, float* limit, int64_t* n_finite, int n_threads) {
+    if (n_threads > 1) {
+        int64_t k = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) reduction(+ : k) num_threads(n_threads)
+#endif
+        for (int64_t i = 0; i < n; ++i) k += (d2[i] != INFINITY) ? 1 : 0;
+        if (n_finite) *n_finite = k;
+        if (k == 0) return -1;
+        *limit = select_kth_radix_mt(d2, n, trim_index(k, ratio), n_threads);
+        return 0;
+    }
     float* v = (float*)malloc((size_t)(n > 0 ? n : 1) * 4);
     int64_t k = 0;
     for (int64_t i = 0; i < n; ++i)
@@ -318,19 +409,12 @@ ORC_API int orc_trim_limit(const float* d2, int64_t n, float ratio, float* limit
         free(v);
         return -1;
     }
-    qsort(v, (size_t)k, 4, cmp_float);
-    if (ratio == 1.0f) {
-        *limit = v[k - 1];
-    } else {
-        /* NC6: `values.size() * quantile` is evaluated in T=float, then truncated */
-        float pos = (float)k * ratio;
-        int64_t idx = (int64_t)pos;
-        if (idx >= k) idx = k - 1;
-        if (idx < 0) idx = 0;
-        *limit = v[idx];
-    }
+    *limit = select_kth(v, k, trim_index(k, ratio));
     free(v);
     return 0;
+}
+ORC_API int orc_trim_limit(const float* d2, int64_t n, float ratio, float* limit, int64_t* n_finite) {
+    return orc_trim_limit_mt(d2, n, ratio, limit, n_finite, 1);
 }
 
 static inline void normalize3(const float n[3], float out[3]) {
@@ -352,6 +436,45 @@ static inline void normalize3(const float n[3], float out[3]) {
     }
 }
 
+/* R3: RigidTransformation::checkParameters / correctParameters (TransformationsImpl.cpp:105-166).
+   |1 - det(R)| > 1e-3 (fp32)  ->  the FEATURES are transformed with a re-orthogonalised copy: col1, col2
+   normalised, newCol0 = col1 x col2, newCol1 = col2 x newCol0, newCol2 = col2, translation kept; descriptors
+   (normals) are still rotated with the uncorrected R (TransformationsImpl.cpp:83-101) and the composed result
+   (ICP.cpp:1345) keeps the uncorrected matrix.  The determinant is the first-row cofactor expansion in fp32 (the
+   reference's dynamic-size Eigen determinant goes through a partial-pivot LU: same value to ~1e-7, threshold 1e-3).
+   Returns 1 when Tc differs from T. */
+static int rigid_correct(const float T[16], float Tc[16]) {
+    memcpy(Tc, T, 64);
+    float m0 = T[5] * T[10], m1 = T[6] * T[9];
+    float c0 = m0 - m1;
+    m0 = T[4] * T[10]; m1 = T[6] * T[8];
+    float c1 = m0 - m1;
+    m0 = T[4] * T[9]; m1 = T[5] * T[8];
+    float c2 = m0 - m1;
+    float a = T[0] * c0, b = T[1] * c1;
+    float det = a - b;
+    a = T[2] * c2;
+    det = det + a;
+    float dev = 1.0f - det;
+    if (!(fabsf(dev) > 0.001f)) return 0;
+    float col1[3] = {T[1], T[5], T[9]}, col2[3] = {T[2], T[6], T[10]}, n1[3], n2[3], n0[3], m1v[3];
+    normalize3(col1, n1);
+    normalize3(col2, n2);
+    float u, v;
+    u = n1[1] * n2[2]; v = n1[2] * n2[1]; n0[0] = u - v;
+    u = n1[2] * n2[0]; v = n1[0] * n2[2]; n0[1] = u - v;
+    u = n1[0] * n2[1]; v = n1[1] * n2[0]; n0[2] = u - v;
+    u = n2[1] * n0[2]; v = n2[2] * n0[1]; m1v[0] = u - v;
+    u = n2[2] * n0[0]; v = n2[0] * n0[2]; m1v[1] = u - v;
+    u = n2[0] * n0[1]; v = n2[1] * n0[0]; m1v[2] = u - v;
+    for (int r = 0; r < 3; ++r) {
+        Tc[4 * r + 0] = n0[r];
+        Tc[4 * r + 1] = m1v[r];
+        Tc[4 * r + 2] = n2[r];
+    }
+    return 1;
+}
+
 /* chain flags */
 #define ORC_F_TRIM 1
 #define ORC_F_NORMAL 2
@@ -365,14 +488,17 @@ typedef struct {
 } orc_filters;
 
 /* weights (0/1) for every source point; returns -1 on the reference's ConvergenceError */
-ORC_API int orc_weights(const orc_filters* f, const float* src_nrm, int64_t nrm_stride, const float* tgt_nrm,
-                        int64_t tnrm_stride, const float T[16], const int32_t* ids, const float* d2, int64_t n,
-                        float* w, float* trim_limit_out) {
+ORC_API int orc_weights_mt(const orc_filters* f, const float* src_nrm, int64_t nrm_stride, const float* tgt_nrm,
+                           int64_t tnrm_stride, const float T[16], const int32_t* ids, const float* d2, int64_t n,
+                           float* w, float* trim_limit_out, int n_threads) {
     float limit = INFINITY;
     if (f->flags & ORC_F_TRIM) {
-        if (orc_trim_limit(d2, n, f->trim_ratio, &limit, NULL) != 0) return -1;
+        if (orc_trim_limit_mt(d2, n, f->trim_ratio, &limit, NULL, n_threads) != 0) return -1;
     }
     if (trim_limit_out) *trim_limit_out = limit;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(n_threads > 0 ? n_threads : 1)
+#endif
     for (int64_t i = 0; i < n; ++i) {
         float wi;
         if (f->flags == 0) {
@@ -402,7 +528,13 @@ ORC_API int orc_weights(const orc_filters* f, const float* src_nrm, int64_t nrm_
         }
         w[i] = wi;
     }
+    (void)n_threads;
     return 0;
+}
+ORC_API int orc_weights(const orc_filters* f, const float* src_nrm, int64_t nrm_stride, const float* tgt_nrm,
+                        int64_t tnrm_stride, const float T[16], const int32_t* ids, const float* d2, int64_t n,
+                        float* w, float* trim_limit_out) {
+    return orc_weights_mt(f, src_nrm, nrm_stride, tgt_nrm, tnrm_stride, T, ids, d2, n, w, trim_limit_out, 1);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -943,10 +1075,12 @@ ORC_API int orc_icp_p2pl(const float* tgt_xyz, int64_t tgt_stride, const float* 
     memcpy(res->T_refMean_readMean, T0, 64);
     float* rd = (float*)malloc((size_t)n * 12);
     float* rdn = src_nrm ? (float*)malloc((size_t)n * 12) : NULL;
+    float T0c[16];
+    rigid_correct(T0, T0c); /* R3: features use the re-orthogonalised copy, descriptors the matrix as given */
     for (int64_t i = 0; i < n; ++i) {
         float p[3];
         for (int k = 0; k < 3; ++k) p[k] = src_xyz[i * src_stride + k] - cread[k];
-        xform_point(T0, p, rd + 3 * i);
+        xform_point(T0c, p, rd + 3 * i);
         if (rdn) rot_vec(T0, src_nrm + i * snrm_stride, rdn + 3 * i);
     }
     int32_t* ids = (int32_t*)malloc((size_t)n * 4);
@@ -966,7 +1100,7 @@ ORC_API int orc_icp_p2pl(const float* tgt_xyz, int64_t tgt_stride, const float* 
     const double t_loop0 = now_s();
     while (iterate) {
         orc_knn(tree, rd, 3, n, T_iter, P->max_dist, ids, d2, P->n_threads);
-        if (orc_weights(&P->filt, rdn, 3, tgt_nrm, tnrm_stride, T_iter, ids, d2, n, w, NULL) != 0) {
+        if (orc_weights_mt(&P->filt, rdn, 3, tgt_nrm, tnrm_stride, T_iter, ids, d2, n, w, NULL, P->n_threads) != 0) {
             status = 3;
             break;
         }

@@ -131,26 +131,28 @@ def make_filters(trim_ratio=None, max_normal_angle=None, outlier_max_dist=None) 
     return f
 
 
-def trim_limit(d2, ratio):
+def trim_limit(d2, ratio, n_threads=1):
+    """n_threads <= 1: nth_element-class selection as the reference (Matches.cpp:83); > 1: parallel exact radix select."""
     d2 = _f32(d2)
     lim = C.c_float()
     nf = C.c_int64()
-    rc = lib().orc_trim_limit(_p(d2), C.c_int64(d2.shape[0]), C.c_float(ratio), C.byref(lim), C.byref(nf))
+    rc = lib().orc_trim_limit_mt(_p(d2), C.c_int64(d2.shape[0]), C.c_float(ratio), C.byref(lim), C.byref(nf),
+                                 C.c_int(n_threads))
     if rc != 0:
         raise RuntimeError("ConvergenceError: no matches available for computing distance quantiles")
     return lim.value, nf.value
 
 
-def weights(filters: Filters, src_nrm, tgt_nrm, T, ids, d2):
+def weights(filters: Filters, src_nrm, tgt_nrm, T, ids, d2, n_threads=1):
     n = ids.shape[0]
     w = np.empty(n, np.float32)
     sn = _f32(src_nrm) if src_nrm is not None else None
     tn = _f32(tgt_nrm) if tgt_nrm is not None else None
     T = _f32(T).reshape(16)
     lim = C.c_float()
-    rc = lib().orc_weights(C.byref(filters), _p(sn), C.c_int64(sn.shape[1] if sn is not None else 3), _p(tn),
-                           C.c_int64(tn.shape[1] if tn is not None else 3), _p(T), _p(ids), _p(_f32(d2)),
-                           C.c_int64(n), _p(w), C.byref(lim))
+    rc = lib().orc_weights_mt(C.byref(filters), _p(sn), C.c_int64(sn.shape[1] if sn is not None else 3), _p(tn),
+                              C.c_int64(tn.shape[1] if tn is not None else 3), _p(T), _p(ids), _p(_f32(d2)),
+                              C.c_int64(n), _p(w), C.byref(lim), C.c_int(n_threads))
     if rc != 0:
         raise RuntimeError("ConvergenceError: no matches available for computing distance quantiles")
     return w, lim.value

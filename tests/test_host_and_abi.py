@@ -15,7 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_library_exports_every_declared_symbol():
-    hdr = open(os.path.join(ROOT, "include", "o3dslam_reg.h")).read()
+    hdr = "".join(open(os.path.join(ROOT, "include", f)).read() for f in sorted(os.listdir(os.path.join(ROOT, "include")))
+                  if f.endswith(".h"))   # the drop-in boundary (o3dslam_reg.h) + the experiment switches (o3dslam_reg_debug.h)
     declared = set(re.findall(r"REG_API\s+[\w\s\*]+?\b(reg_\w+)\s*\(", hdr))
     assert len(declared) >= 20
     lib = capi.load_library()
@@ -34,6 +35,12 @@ def test_param_struct_layout_and_defaults():
     # open3d_slam_ros/param/icp.yaml
     assert abs(s.max_dist - 0.5) < 1e-6 and abs(s.trim_ratio - 0.9) < 1e-6 and s.use_surface_normal == 1
     assert s.max_iter == 30 and abs(s.min_diff_trans - 0.008) < 1e-6
+    # the experiment switches are no longer part of the public struct (include/o3dslam_reg_debug.h)
+    public = {f[0] for f in capi.RegParams._fields_}
+    assert not public & {"match_variant", "debug_flags", "lanes_per_point", "disable_halo", "disable_fused", "profile_loop"}
+    hdr = open(os.path.join(ROOT, "include", "o3dslam_reg.h")).read()
+    body = hdr[hdr.index("typedef struct {", hdr.index("Configuration ==")):hdr.index("} reg_params;")]
+    assert [m for m in re.findall(r"^\s+(?:int32_t|float)\s+(\w+)", body, re.M)] == [f[0] for f in capi.RegParams._fields_]
 
 
 def test_host_solver_matches_oracle_and_numpy():
@@ -248,4 +255,5 @@ transformationCheckers:
     with pytest.raises(icp.InvalidParameter):       # a missing threshold fails the load (ICP.cpp:632-672 return false)
         m.loadFromYaml(y.replace("    enoughInformationThreshold: 250\n", ""))
     d = capi.shipped_params()
-    assert d.use_xicp == 0 and d.xicp_enough == 250 and d.xicp_strong_angle_deg == 45
+    assert d.use_xicp == 1 and d.xicp_enough == 250 and d.xicp_strong_angle_deg == 45   # the shipped chain has it on
+    assert capi.default_params().use_xicp == 0                                           # setDefault() does not

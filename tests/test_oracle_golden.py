@@ -188,3 +188,55 @@ def test_surface_normals_oracle_against_numpy_and_stored_normals(car):
     C[:, iu[1], iu[0]] = c2[sel]
     w = np.linalg.eigvalsh(C)
     assert np.allclose(w, [[1e-3, 1, 1]], rtol=1e-4)
+
+
+def test_trim_limit_selection_variants_agree():
+    """Matches::getDistsQuantile (Matches.cpp:60-87): the nth_element-class serial selection (the reference's own
+    algorithm class) and the multi-threaded exact radix selection of the OpenMP baseline leg give the value a full
+    sort gives, for every ratio, with +inf entries and ties."""
+    rng = np.random.default_rng(9)
+    for n in (1, 2, 17, 1000, 65537):
+        d2 = (rng.random(n).astype(np.float32) ** 3).astype(np.float32)
+        d2[rng.random(n) < 0.1] = np.inf
+        d2[rng.random(n) < 0.05] = np.float32(0.125)          # ties
+        fin = np.sort(d2[np.isfinite(d2)])
+        for ratio in (0.0, 0.5, 0.85, 0.9, 0.999, 1.0):
+            if fin.size == 0:
+                with pytest.raises(RuntimeError):
+                    orc.trim_limit(d2, ratio)
+                continue
+            k = fin.size - 1 if np.float32(ratio) == 1 else min(int(np.float32(fin.size) * np.float32(ratio)), fin.size - 1)
+            want = fin[k]
+            for nt in (1, 4):
+                lim, nf = orc.trim_limit(d2, ratio, n_threads=nt)
+                assert nf == fin.size
+                assert np.float32(lim) == want, (n, ratio, nt, lim, want)
+
+
+def test_rigid_correction_restates_correctParameters():
+    """R3 (TransformationsImpl.cpp:105-166): |1 - det| > 1e-3 -> col1, col2 normalised, newCol0 = col1 x col2,
+    newCol1 = col2 x newCol0, newCol2 = col2.  Checked through the oracle's registration: a sheared prior and its
+    hand-corrected twin bring the reading's points to the same place, so the first linearisation (A, b) agrees."""
+    sc = synth.make_scene(2000, 20000, seed=4)
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3] = synth.rpy_to_R(0.01, 0.02, -0.015).astype(np.float32)
+    T[:3, 1] *= np.float32(1.02)
+    T[:3, 3] = (0.05, 0.0, -0.02)
+    c1 = T[:3, 1] / np.linalg.norm(T[:3, 1])
+    c2 = T[:3, 2] / np.linalg.norm(T[:3, 2])
+    n0 = np.cross(c1, c2)
+    n1 = np.cross(c2, n0)
+    Tc = T.copy()
+    Tc[:3, 0], Tc[:3, 1], Tc[:3, 2] = n0, n1, c2
+    assert abs(np.linalg.det(Tc[:3, :3].astype(np.float64)) - 1) < 1e-5 < 1e-3 < abs(np.linalg.det(T[:3, :3].astype(np.float64)) - 1)
+    kw = dict(max_dist=0.5, trim_ratio=0.9, fixed_iters=1)        # no normal filter: normals keep the uncorrected R
+    _, ra = orc.icp_p2pl(sc.tgt_xyz, sc.tgt_nrm, sc.src_xyz, None, T, **kw)
+    _, rb = orc.icp_p2pl(sc.tgt_xyz, sc.tgt_nrm, sc.src_xyz, None, Tc, **kw)
+    A, B = np.array(ra.A_last), np.array(rb.A_last)
+    assert np.abs(A - B).max() <= 1e-4 * np.abs(B).max()
+    assert ra.n_kept_last == pytest.approx(rb.n_kept_last, rel=1e-3)
+    # and a sheared prior is NOT the same as an unsheared one without the correction being the reason they agree
+    T2 = T.copy()
+    T2[:3, 1] /= np.float32(1.02)
+    _, rc = orc.icp_p2pl(sc.tgt_xyz, sc.tgt_nrm, sc.src_xyz, None, T2, **kw)
+    assert np.abs(np.array(rc.A_last) - B).max() <= 2e-2 * np.abs(B).max()
