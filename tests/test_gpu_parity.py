@@ -372,6 +372,7 @@ def test_stream_ordered_distributed_path_two_slices_one_gpu():
     from open3d_slam_private_amd.distributed import StreamDistributedRegistration, _DevArray
     sc = synth.make_scene(12000, 120000, seed=41)
     p = capi.shipped_params()
+    p.use_xicp = 0     # the plain chain's phases (the R8x phases 7-9 have their own test in test_gpu_xicp.py)
     p.fixed_iters = 8
     p.disable_fused = 1     # the distributed loop is the generic (select-based) path: compare like with like
     whole = capi.Registration(p)
@@ -676,6 +677,7 @@ def test_fused_multi_gpu_iteration_two_slices_one_gpu():
     from open3d_slam_private_amd.distributed import _DevArray
     sc = synth.make_scene(12000, 120000, seed=51)
     p = capi.shipped_params()
+    p.use_xicp = 0     # the plain chain's phases (the R8x phases 7-9 have their own test in test_gpu_xicp.py)
     p.fixed_iters = 12
     whole = capi.Registration(p)
     whole.set_target(sc.tgt_xyz, sc.tgt_nrm)
@@ -779,6 +781,7 @@ def test_select_by_gather_iteration_two_uneven_slices_one_gpu():
     from open3d_slam_private_amd.distributed import _DevArray
     sc = synth.make_scene(12000, 120000, seed=43)
     p = capi.shipped_params()
+    p.use_xicp = 0     # the plain chain's phases (the R8x phases 7-9 have their own test in test_gpu_xicp.py)
     p.fixed_iters = 7
     p.disable_fused = 1
     whole = capi.Registration(p)
