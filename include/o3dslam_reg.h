@@ -253,6 +253,55 @@ REG_API reg_status reg_dist_gather_buffers(reg_handle* h, int n_ranks, int64_t n
    *center, phase 8, all-reduce the 12 doubles at *sums, phase 9 (reports with the sequence number of phase 4). */
 REG_API reg_status reg_dist_xicp_buffers(reg_handle* h, void** center, void** sums);
 
+/* ---- multi-GPU registration behind the C ABI (BASELINE config C4) ---------------------------------
+   One process per GPU.  The reading is point-partitioned: every rank gives ITS slice to reg_set_source; the reference
+   (reg_set_target) and its tables are replicated.  reg_dist_register is ICP::compute (ICP.cpp:813-844, called from
+   the C++ mapper, Mapper.cpp:343,372-373) for that layout: all kernels and collectives are enqueued on the handle's
+   stream, nothing synchronises inside an iteration, and every rank returns the same T_out.  Per iteration the ranks
+   exchange, over RCCL (xGMI): unsettled iterations -- one all-gather of the squared match distances (exact global
+   trimmed quantile, selected redundantly on every rank) + one all-reduce of the 32-double (H, b, e, counts) record;
+   settled iterations -- ONE all-gather of a fixed-size block {32 sums, band records} per rank.
+   Group set-up: rank 0 calls reg_dist_get_unique_id and hands the 128 bytes to the other ranks by any means (MPI,
+   a file, torch.distributed ...); every rank then calls reg_dist_init (ncclCommInitRank on the handle's device).
+   COLLECTIVE CONTRACT: all ranks call reg_dist_init / reg_dist_register / reg_dist_shutdown in the same order, and a
+   new reading is set on ALL ranks or on none between two registrations.  Every wait inside reg_dist_register has a
+   deadline (O3D_DIST_TIMEOUT_S, default 30 s): a dead peer or a collective that never completes returns
+   REG_DEVICE_ERROR on the survivors instead of hanging them -- the caller should then exit non-zero. */
+#define REG_DIST_ID_BYTES 128
+REG_API reg_status reg_dist_get_unique_id(char id[REG_DIST_ID_BYTES]);
+REG_API reg_status reg_dist_init(reg_handle* h, const char id[REG_DIST_ID_BYTES], int rank, int n_ranks);
+REG_API reg_status reg_dist_register(reg_handle* h, const float T_init[16], float T_out[16], reg_result* res);
+REG_API reg_status reg_dist_shutdown(reg_handle* h);
+/* after reg_dist_register: size of the whole reading and how the loop went (any pointer may be NULL) */
+REG_API reg_status reg_dist_info(reg_handle* h, int64_t* n_global, int32_t* n_generic, int32_t* n_fused, int32_t* n_stalls);
+/* A transport other than RCCL (tests on one GPU, other launchers): both callbacks ENQUEUE on `stream` (or complete
+   before returning), operate in place on DEVICE memory and return 0 on success. */
+enum { REG_DT_I32 = 0, REG_DT_I64 = 1, REG_DT_F64 = 2 };
+typedef struct {
+    void* ctx;
+    int (*all_reduce_sum)(void* ctx, void* buf, int64_t count, int dtype, void* stream);
+    int (*all_gather)(void* ctx, const void* send, void* recv, int64_t bytes_per_rank, void* stream);
+} reg_collectives;
+REG_API reg_status reg_dist_init_custom(reg_handle* h, const reg_collectives* c, int rank, int n_ranks);
+
+/* The steering of reg_dist_register as a pure host-side state machine (no device, no collectives), exported so that
+   the decision logic every rank must agree on can be exercised without a GPU (world_size-2 gloo tests on CPU):
+   step() consumes the reply to its previous action and returns the next one.
+     REG_STEER_RECORD  wait for the record of sequence `seq` (reg_dist_record); reply.available = 0 when the stream
+                       drained without it (an earlier sequence ended or stalled the loop)
+     REG_STEER_GENERIC enqueue one select-based iteration (no reply)
+     REG_STEER_FUSED   enqueue `count` fused iterations (no reply)
+     REG_STEER_DRAIN   wait until the stream is idle, reply with the latest state (reg_dist_poll)
+     REG_STEER_DONE    the registration is complete */
+enum { REG_STEER_RECORD = 0, REG_STEER_GENERIC = 1, REG_STEER_FUSED = 2, REG_STEER_DRAIN = 3, REG_STEER_DONE = 4 };
+typedef struct { int32_t kind, count; int64_t seq; } reg_dist_action;
+typedef struct { int32_t available, iterations, done, stall; float limit_last, limit_prev; } reg_dist_reply;
+typedef struct reg_dist_steer reg_dist_steer;
+REG_API reg_dist_steer* reg_dist_steer_create(int trimming, int fixed_iters, int max_iter, float settle_tol, int can_fuse);
+REG_API void reg_dist_steer_destroy(reg_dist_steer* s);
+REG_API reg_dist_action reg_dist_steer_step(reg_dist_steer* s, const reg_dist_reply* reply /* NULL on the first call */);
+REG_API void reg_dist_steer_counts(const reg_dist_steer* s, int32_t* n_generic, int32_t* n_fused, int32_t* n_stalls);
+
 /* Host-side pieces of the path, exported so they can be checked without a GPU
    (PointToPlane.cpp:112-265 solve, :327-381 x -> 4x4; column-major 4x4). */
 REG_API int  reg_host_solve6(const float A[36], const float b[6], float x[6]);

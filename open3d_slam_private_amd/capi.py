@@ -77,6 +77,26 @@ class DistStatus(C.Structure):
                 ("limit_prev", C.c_float)]
 
 
+class DistAction(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("count", C.c_int32), ("seq", C.c_int64)]
+
+
+class DistReply(C.Structure):
+    _fields_ = [("available", C.c_int32), ("iterations", C.c_int32), ("done", C.c_int32), ("stall", C.c_int32),
+                ("limit_last", C.c_float), ("limit_prev", C.c_float)]
+
+
+STEER_RECORD, STEER_GENERIC, STEER_FUSED, STEER_DRAIN, STEER_DONE = 0, 1, 2, 3, 4
+DT_I32, DT_I64, DT_F64 = 0, 1, 2
+DIST_ID_BYTES = 128
+ALL_REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+
+
+class Collectives(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("all_reduce_sum", ALL_REDUCE_FN), ("all_gather", ALL_GATHER_FN)]
+
+
 class TargetInfo(C.Structure):
     _fields_ = [("n_points", C.c_int64), ("n_bricks", C.c_int64), ("n_cells_occupied", C.c_int64),
                 ("table_bytes", C.c_int64), ("cell_size", C.c_float), ("origin", C.c_float * 3),
@@ -91,7 +111,10 @@ EXPORTS = ["reg_default_params", "reg_shipped_params", "reg_create", "reg_destro
            "reg_dist_fused_buffers", "reg_dist_poll", "reg_estimate_normals", "reg_host_solve6_xicp",
            "reg_set_target_f64", "reg_get_target_source_indices", "reg_voxelize_within_volume", "reg_carve_indices", "reg_dist_xicp_buffers", "reg_dist_gather_buffers",
            "reg_dist_record", "reg_dist_centroid_sums", "reg_dist_prepare",
-           "reg_information_matrix", "reg_set_source_f64", "reg_debug_configure"]
+           "reg_information_matrix", "reg_set_source_f64", "reg_debug_configure",
+           "reg_dist_get_unique_id", "reg_dist_init", "reg_dist_init_custom", "reg_dist_register", "reg_dist_shutdown",
+           "reg_dist_info", "reg_dist_steer_create", "reg_dist_steer_destroy", "reg_dist_steer_step",
+           "reg_dist_steer_counts"]
 
 
 def lib_path() -> str:
@@ -130,6 +153,20 @@ def load_library():
     lib.reg_last_error.restype = C.c_char_p
     lib.reg_set_stream.argtypes = [vp, vp]
     lib.reg_debug_configure.argtypes = [vp, C.POINTER(RegDebugParams)]
+    lib.reg_dist_get_unique_id.argtypes = [C.c_char_p]
+    lib.reg_dist_init.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
+    lib.reg_dist_init_custom.argtypes = [vp, C.POINTER(Collectives), C.c_int, C.c_int]
+    lib.reg_dist_register.argtypes = [vp, f32p, f32p, C.POINTER(RegResult)]
+    lib.reg_dist_shutdown.argtypes = [vp]
+    lib.reg_dist_info.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.reg_dist_steer_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]
+    lib.reg_dist_steer_create.restype = vp
+    lib.reg_dist_steer_destroy.argtypes = [vp]
+    lib.reg_dist_steer_destroy.restype = None
+    lib.reg_dist_steer_step.argtypes = [vp, C.POINTER(DistReply)]
+    lib.reg_dist_steer_step.restype = DistAction
+    lib.reg_dist_steer_counts.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.reg_dist_steer_counts.restype = None
     lib.reg_set_source_f64.argtypes = [vp, vp, vp, vp, i64, C.c_int]
     lib.reg_set_target.argtypes = [vp, f32p, i64, f32p, i64, f32p, i64, C.c_int]
     lib.reg_set_source.argtypes = [vp, f32p, i64, f32p, i64, f32p, i64, C.c_int]
@@ -541,6 +578,38 @@ class Registration:
         self._check(st)
         return _T_out(To), res
 
+    # ---- multi-GPU registration behind the C ABI (RCCL, or a custom transport) --------------------------
+    def dist_init(self, unique_id: bytes, rank: int, n_ranks: int):
+        """ncclCommInitRank on the handle's device; `unique_id` = the 128 bytes of dist_unique_id() of rank 0."""
+        buf = C.create_string_buffer(bytes(unique_id), DIST_ID_BYTES)
+        self._check(self._lib.reg_dist_init(self._h, buf, int(rank), int(n_ranks)))
+
+    def dist_init_custom(self, all_reduce_sum, all_gather, rank: int, n_ranks: int):
+        """Transport given as Python callables (buf_ptr, count, dtype, stream) / (send_ptr, recv_ptr, bytes_per_rank,
+        stream) -> 0 on success; both operate on DEVICE memory."""
+        self._cb = (ALL_REDUCE_FN(lambda ctx, buf, n, dt, st: int(all_reduce_sum(buf, n, dt, st))),
+                    ALL_GATHER_FN(lambda ctx, snd, rcv, nb, st: int(all_gather(snd, rcv, nb, st))))
+        c = Collectives(None, self._cb[0], self._cb[1])
+        self._check(self._lib.reg_dist_init_custom(self._h, C.byref(c), int(rank), int(n_ranks)))
+
+    def dist_register(self, T_init=None):
+        """Collective: == ICP::compute for the reading that is partitioned over the ranks of the group."""
+        Ti = _T_in(np.eye(4) if T_init is None else T_init)
+        To = np.zeros(16, np.float32)
+        res = RegResult()
+        st = self._lib.reg_dist_register(self._h, _ptr(Ti), _ptr(To), C.byref(res))
+        self.last_result = res
+        self._check(st)
+        return _T_out(To), res
+
+    def dist_info(self):
+        n, g, f, s = C.c_int64(), C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self._lib.reg_dist_info(self._h, C.byref(n), C.byref(g), C.byref(f), C.byref(s)))
+        return {"n_global": n.value, "n_generic": g.value, "n_fused": f.value, "n_stalls": s.value}
+
+    def dist_shutdown(self):
+        self._check(self._lib.reg_dist_shutdown(self._h))
+
     def match_local(self, T_iter):
         self._check(self._lib.reg_match_local(self._h, _ptr(_T_in(T_iter))))
 
@@ -553,6 +622,40 @@ class Registration:
         sums = np.zeros(32, np.float64)
         self._check(self._lib.reg_reduce_local(self._h, _ptr(_T_in(T_iter)), trim_limit, _ptr(sums)))
         return sums
+
+
+def dist_unique_id() -> bytes:
+    """ncclGetUniqueId (rank 0); hand the 128 bytes to the other ranks by any means."""
+    buf = C.create_string_buffer(DIST_ID_BYTES)
+    st = load_library().reg_dist_get_unique_id(buf)
+    if st != 0:
+        raise RegError(st, "reg_dist_get_unique_id (is librccl loadable?)")
+    return buf.raw
+
+
+class Steer:
+    """The steering state machine of reg_dist_register (pure host code in the library: no device needed)."""
+
+    def __init__(self, trimming, fixed_iters, max_iter, settle_tol=0.05, can_fuse=True):
+        self._lib = load_library()
+        self._s = C.c_void_p(self._lib.reg_dist_steer_create(int(bool(trimming)), int(fixed_iters), int(max_iter),
+                                                             float(settle_tol), int(bool(can_fuse))))
+
+    def step(self, reply: "DistReply | None" = None) -> DistAction:
+        return self._lib.reg_dist_steer_step(self._s, C.byref(reply) if reply is not None else None)
+
+    def counts(self):
+        g, f, s = C.c_int32(), C.c_int32(), C.c_int32()
+        self._lib.reg_dist_steer_counts(self._s, C.byref(g), C.byref(f), C.byref(s))
+        return g.value, f.value, s.value
+
+    def __del__(self):
+        try:
+            if self._s:
+                self._lib.reg_dist_steer_destroy(self._s)
+                self._s = None
+        except Exception:
+            pass
 
 
 def solve_update(params: RegParams, sums, T_iter):

@@ -57,6 +57,8 @@ struct EnvSwitches {
     }
 };
 
+struct DistCtx;   // multi-GPU group state (host_rccl.hpp)
+
 struct reg_handle {
     reg_params prm;
     reg_debug_params dbg;   // experiment switches (include/o3dslam_reg_debug.h); all zero in production
@@ -121,6 +123,8 @@ struct reg_handle {
     unsigned long long dist_seq0 = 0;
     DevBuf d_contrib, d_gathered;     // multi-GPU fused iteration: this rank's block / all ranks' blocks
     int dist_ranks = 0, dist_rank = 0;
+    DistCtx* dist = nullptr;          // reg_dist_init: RCCL communicator (or custom transport) of this handle's group
+    unsigned long long src_epoch = 0; // counts reg_set_source calls (the distributed path re-reads the slice sizes per reading)
     // loop profiling (params.profile_loop): HIP events around the search kernels of every iteration
     std::vector<hipEvent_t> prof_ev;   // pairs (start, stop)
     std::vector<int> prof_kind;        // 0: k_match, 1: k_iter_fused
@@ -239,6 +243,7 @@ reg_status reg_create(const reg_params* p, reg_handle** out) {
 
 void reg_destroy(reg_handle* h) {
     if (!h) return;
+    (void)reg_dist_shutdown(h);
     if (h->normals_ws) reg_destroy(h->normals_ws);
     h->n_out.release();
     h->i_xicp.release();
@@ -1158,6 +1163,7 @@ reg_status reg_set_source(reg_handle* h, const float* xyz, int64_t xyz_stride, c
         if (s != REG_OK) return s;
     }
     h->n = n;
+    ++h->src_epoch;
     h->has_snrm = nrm != nullptr;
     h->has_scov = cov != nullptr;
     // iteration buffers

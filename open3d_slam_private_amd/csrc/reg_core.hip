@@ -42,3 +42,4 @@ using namespace o3dreg;
 #include "host_target.hpp"
 #include "host_loop.hpp"
 #include "host_dist.hpp"
+#include "host_rccl.hpp"

@@ -15,6 +15,7 @@ contract is "same numbers as the single-rank path on the concatenated reading".
 from __future__ import annotations
 
 import math
+import time
 
 import numpy as np
 
@@ -86,6 +87,7 @@ class DistributedRegistration:
         """One Gauss-Newton iteration over all ranks.  Returns (T_next, global sums)."""
         self.local.match_local(T_iter)
         limit = self.global_trim_limit() if self.use_trimmed else math.inf
+        self.last_limit = limit
         sums = self._allreduce(self.local.reduce_local(T_iter, limit))
         return self.solve_update(sums, T_iter), sums
 
@@ -166,14 +168,16 @@ class FusedStreamDistributedRegistration(StreamDistributedRegistration):
     """Stream-ordered multi-GPU loop that switches, once the trimmed limit has settled, from the select-based
     iteration (6 launches + 4 all-reduces) to the fused iteration (2 launches + ONE all-gather of a 66 KB block per
     rank).  The device decides whether a fused iteration was valid (exact verification of the predicted band, on
-    every rank alike); a stalled iteration is repeated on the select-based path.  The host steers by the mirror the
-    update kernel writes (reg_dist_poll) and stays at most `ahead` iterations ahead of it."""
+    every rank alike); a stalled iteration is repeated on the select-based path.  The decisions are taken by the
+    library's own steering state machine (capi.Steer == reg_dist_steer_*, the code reg_dist_register runs in C++); this
+    class only carries them out with torch.distributed collectives.  Kept for rehearsals with non-RCCL backends: the
+    production N > 1 path is capi.Registration.dist_register."""
 
     def __init__(self, reg, use_trimmed, trim_ratio, iters, world, rank, dist=None, device=None, all_reduce=None,
-                 all_gather=None, ahead=3, fixed=True, settle_tol=0.05, gather_select=True, n_max=None):
+                 all_gather=None, fixed=True, settle_tol=0.05, gather_select=True, n_max=None, timeout_s=30.0):
         super().__init__(reg, use_trimmed, iters, dist=dist, device=device, all_reduce=all_reduce)
         import torch
-        self.world, self.rank, self.ahead, self.fixed, self.settle_tol = world, rank, ahead, fixed, settle_tol
+        self.world, self.rank, self.fixed, self.settle_tol, self.timeout_s = world, rank, fixed, settle_tol, timeout_s
         # settle_tol: stricter than the single-GPU loop's 25 % -- a rank's contribution block holds at most 512 band
         # records, and the band of the first fused iterations is as wide as the limit still moves (measured: at 25 % the
         # first fused iteration overflowed the block, stalled, and the whole burst behind it ran as no-ops)
@@ -225,18 +229,21 @@ class FusedStreamDistributedRegistration(StreamDistributedRegistration):
         reg.dist_phase(4)
         if self._xicp_first:
             self._xicp_analysis()
-        self.n_generic += 1
 
     def _fused(self):
         self.reg.dist_phase(5)
         self._ag(self.gathered, self.contrib)
         self.reg.dist_phase(6)
-        self.n_fused += 1
+
+    def _deadline(self):
+        return time.monotonic() + self.timeout_s
 
     def _record(self, seq_rel):
         """Blocks until sequence `seq_rel` has reported (returns its record) or can no longer report because the stream
-        drained without it (returns None: an earlier sequence ended or stalled the loop)."""
+        drained without it (returns None: an earlier sequence ended or stalled the loop).  Raises after `timeout_s`: a
+        dead peer or a collective that never completes must not spin the survivors forever."""
         reg = self.reg
+        t_end = self._deadline()
         while True:
             st = reg.dist_record(seq_rel)
             if int(st.sequences_done) == seq_rel:
@@ -244,64 +251,88 @@ class FusedStreamDistributedRegistration(StreamDistributedRegistration):
             if st.stream_idle:
                 st = reg.dist_record(seq_rel)          # the report may have landed between the two reads
                 return st if int(st.sequences_done) == seq_rel else None
+            if time.monotonic() > t_end:
+                raise TimeoutError(f"sequence {seq_rel} of the distributed loop did not report within {self.timeout_s} s "
+                                   "(a peer rank died or a collective never completed)")
 
-    def _settled(self, rec):
-        if not self.trimming:
-            return True
-        return (rec is not None and math.isfinite(rec.limit_prev) and math.isfinite(rec.limit_last) and
-                abs(rec.limit_last - rec.limit_prev) <= self.settle_tol * rec.limit_last)
+    def _drain(self):
+        reg = self.reg
+        t_end = self._deadline()
+        while not reg.dist_poll().stream_idle:
+            if time.monotonic() > t_end:
+                raise TimeoutError(f"the stream of the distributed loop did not drain within {self.timeout_s} s")
+        return reg.dist_poll()
 
     def run(self, T_start=None):
-        """Every decision (select-based or fused iteration, stop, repair) is taken from the record of ONE specific
-        sequence -- the second to last enqueued -- which is the same on every rank; nothing depends on how far the
-        device happens to be when the host looks.  Ranks therefore always enqueue the same collectives."""
+        """Every decision (select-based or fused iteration, stop, repair) is taken by the library's steering state
+        machine (reg_dist_steer_*, the SAME code reg_dist_register runs) from the record of ONE specific sequence,
+        which is identical on every rank; nothing depends on how far the device happens to be when the host looks.
+        Ranks therefore always enqueue the same collectives."""
+        from . import capi
         reg = self.reg
         reg.dist_begin(T_start)
         self._xicp_first = self.use_xicp
-        limit = self.iters
-        enq = 0            # sequences enqueued since dist_begin
-        base_it = 0        # iterations completed at the last repair point ...
-        base_seq = 0       # ... and the sequence count at that point
-        generic_left = 2 if self.trimming else 1
+        steer = capi.Steer(self.trimming, self.iters if self.fixed else 0, self.iters, self.settle_tol, True)
+        reply = None
         while True:
-            planned = base_it + (enq - base_seq)       # iterations completed once everything enqueued has run
-            rec = None
-            if enq - base_seq >= 2:
-                rec = self._record(enq - 1)             # the second to last sequence
-                if rec is None or rec.stall:
-                    # an earlier sequence stalled (band misprediction) or ended the loop: drain, look at the outcome
-                    while not reg.dist_poll().stream_idle:
-                        pass
-                    top = reg.dist_poll()
-                    if top.done:
-                        break
-                    base_it, base_seq = int(top.iterations), enq
-                    generic_left = 2
-                    self.n_stalls += 1
-                    continue
-                if rec.done:
-                    break
-            if planned >= limit:
-                # everything is enqueued: wait for the last report (or a stall in the burst)
-                last = self._record(enq) if enq > base_seq else None
-                if enq > base_seq and (last is None or last.stall):
-                    while not reg.dist_poll().stream_idle:
-                        pass
-                    top = reg.dist_poll()
-                    if top.done or int(top.iterations) >= limit:
-                        break
-                    base_it, base_seq = int(top.iterations), enq
-                    generic_left = 2
-                    self.n_stalls += 1
-                    continue
+            a = steer.step(reply)
+            reply = None
+            if a.kind == capi.STEER_DONE:
                 break
-            if generic_left > 0 or not self._settled(rec):
+            if a.kind == capi.STEER_RECORD:
+                rec = self._record(int(a.seq))
+                reply = capi.DistReply()
+                if rec is not None:
+                    reply.available, reply.iterations, reply.done, reply.stall = 1, int(rec.iterations), int(rec.done), int(rec.stall)
+                    reply.limit_last, reply.limit_prev = float(rec.limit_last), float(rec.limit_prev)
+            elif a.kind == capi.STEER_DRAIN:
+                top = self._drain()
+                reply = capi.DistReply()
+                reply.available, reply.iterations, reply.done, reply.stall = 1, int(top.iterations), int(top.done), int(top.stall)
+                reply.limit_last, reply.limit_prev = float(top.limit_last), float(top.limit_prev)
+            elif a.kind == capi.STEER_GENERIC:
                 self._generic()
-                generic_left = max(generic_left - 1, 0)
-                enq += 1
             else:
-                burst = (limit - planned) if self.fixed else 1
-                for _ in range(max(burst, 1)):
+                for _ in range(int(a.count)):
                     self._fused()
-                    enq += 1
+        self.n_generic, self.n_fused, self.n_stalls = steer.counts()
         return reg.dist_finish()
+
+
+def host_staged_transport(dist, device, group=None):
+    """(all_reduce_sum, all_gather) callables for capi.Registration.dist_init_custom that move the bytes with ANY
+    torch.distributed backend through host staging (gloo on a box where RCCL cannot be used, e.g. several ranks sharing
+    one GPU in a rehearsal).  Slow by construction (device -> host -> network -> device with full synchronisation); the
+    production transport is RCCL inside the library (capi.Registration.dist_init)."""
+    import torch
+    from . import capi
+    typ = {capi.DT_I32: "<i4", capi.DT_I64: "<i8", capi.DT_F64: "<f8"}
+    world = dist.get_world_size(group)
+
+    def all_reduce(buf, count, dtype, stream):
+        try:
+            torch.cuda.synchronize(device)
+            t = torch.as_tensor(_DevArray(buf, (int(count),), typ[dtype]), device=device)
+            c = t.cpu()
+            dist.all_reduce(c, group=group)
+            t.copy_(c)
+            torch.cuda.synchronize(device)
+            return 0
+        except Exception:   # noqa: BLE001 -- reported to the library as a failed collective
+            return 1
+
+    def all_gather(send, recv, nbytes, stream):
+        try:
+            torch.cuda.synchronize(device)
+            nbytes = int(nbytes)
+            s_ = torch.as_tensor(_DevArray(send, (nbytes,), "|u1"), device=device).cpu()
+            parts = [torch.empty_like(s_) for _ in range(world)]
+            dist.all_gather(parts, s_, group=group)
+            out = torch.as_tensor(_DevArray(recv, (world * nbytes,), "|u1"), device=device)
+            out.copy_(torch.cat(parts))
+            torch.cuda.synchronize(device)
+            return 0
+        except Exception:   # noqa: BLE001
+            return 1
+
+    return all_reduce, all_gather

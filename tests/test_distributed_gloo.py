@@ -91,8 +91,60 @@ def _worker(rank, world, port, out_path):
     from oracle import oracle as orc
     lim_global, _ = orc.trim_limit(np.concatenate(d2_all), p.trim_ratio)
     assert np.float32(lim_dist) == np.float32(lim_global), (lim_dist, lim_global)
+    # ---- the SAME steering code the C++ multi-GPU loop runs (reg_dist_steer_* through capi.Steer), over gloo -------
+    # A stream-ordered "device" per rank: every enqueued sequence runs in order (one oracle iteration with the global
+    # collectives) and reports a record unless the loop is done or stalled -- what k_reduce_update does.  A scripted
+    # band misprediction stalls sequence STALL_SEQ on every rank alike.
+    STALL_SEQ, N_IT = 6, 9
+    st = capi.Steer(True, N_IT, 30, 0.5, True)          # settle tolerance 50 %: fused iterations start early
+    dev = {"T": np.eye(4, dtype=np.float32), "it": 0, "done": 0, "stall": 0, "lims": [math.inf], "rec": {}, "seq": 0,
+           "top": None, "actions": []}
+    dreg2 = DistributedRegistration(back, solve, True, p.trim_ratio, N_IT, dist=dist)
+
+    def run_seq(kind):
+        dev["seq"] += 1
+        dev["actions"].append(kind)
+        if dev["done"] or (kind == "fused" and dev["stall"]):
+            return                                           # no-op: does not report
+        if kind == "fused" and dev["seq"] == STALL_SEQ:
+            dev["stall"] = 1
+            rec = (dev["it"], 0, 1)
+        else:
+            dev["stall"] = 0
+            dev["T"], dev["sums"] = dreg2.iterate(dev["T"])    # collective on every rank
+            dev["lims"].append(float(dreg2.last_limit))
+            dev["it"] += 1
+            dev["done"] = int(dev["it"] >= N_IT)
+            rec = (dev["it"], dev["done"], 0)
+        lims = dev["lims"]
+        top = capi.DistReply(1, rec[0], rec[1], rec[2], lims[-1], lims[-2] if len(lims) > 1 else math.inf)
+        dev["rec"][dev["seq"]] = top
+        dev["top"] = top
+
+    reply = None
+    for _guard in range(200):
+        a = st.step(reply)
+        reply = None
+        if a.kind == capi.STEER_DONE:
+            break
+        if a.kind == capi.STEER_RECORD:
+            reply = dev["rec"].get(int(a.seq), capi.DistReply(0, 0, 0, 0, math.inf, math.inf))
+        elif a.kind == capi.STEER_DRAIN:
+            reply = dev["top"]
+        elif a.kind == capi.STEER_GENERIC:
+            run_seq("generic")
+        else:
+            for _ in range(int(a.count)):
+                run_seq("fused")
+    else:
+        raise AssertionError("the steering did not finish")
+    acts = [None] * world
+    dist.all_gather_object(acts, dev["actions"])
+    assert all(a == acts[0] for a in acts), "ranks enqueued different sequences"
+    assert dev["it"] == N_IT and dev["done"] == 1
+    assert "fused" in dev["actions"] and st.counts()[2] == 1          # one stall, repaired
     if rank == 0:
-        np.save(out_path, np.concatenate([T_iter.ravel(), sums, [lim_global], c_read]))
+        np.save(out_path, np.concatenate([T_iter.ravel(), sums, [lim_global], c_read, dev["T"].ravel()]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -126,6 +178,12 @@ def test_two_rank_gloo_matches_single_process_oracle():
     assert int(round(sums[28])) == res.n_kept_last
     # global centroid identical to the single-process one
     assert np.array_equal(got[49:52].astype(np.float32), orc.centroid(sc.src_xyz))
+    # the loop driven by the library's steering state machine (9 iterations, one stalled sequence repaired)
+    T9 = got[52:68].reshape(4, 4)
+    _, res9 = orc.icp_p2pl(sc.tgt_xyz, sc.tgt_nrm, sc.src_xyz, sc.src_nrm, max_dist=p.max_dist,
+                           trim_ratio=p.trim_ratio, max_normal_angle=p.max_normal_angle, fixed_iters=9)
+    dt, dr = synth.pose_error(T9, np.array(res9.T_iter, np.float32).reshape(4, 4))
+    assert dt <= 1e-5 and dr <= 1e-5, (dt, dr)
 
 
 def test_select_from_hist_and_trim_rank():

@@ -1,0 +1,209 @@
+"""reg_dist_register -- the multi-GPU registration loop behind the C ABI (C++ steering + kernels + collectives on one
+stream) -- on the one GPU of the test box:
+
+  * a real RCCL communicator with ONE rank (ncclCommInitRank through the library's lazily loaded librccl);
+  * TWO ranks as two handles in two host threads sharing the GPU, with an in-process transport (reg_dist_init_custom)
+    standing in for RCCL: the C++ loop, the record-driven steering, the fused / select-by-gather iterations and the R8x
+    phases run exactly as they would over xGMI; only the bytes travel differently.
+
+Expected: every rank returns the same pose, equal to the single-handle registration of the whole reading (same
+numbers by construction: exact global centroid, exact global quantile, fixed-order reduction)."""
+import threading
+
+import numpy as np
+import pytest
+
+from open3d_slam_private_amd import capi, synth
+from open3d_slam_private_amd.distributed import _DevArray
+
+pytestmark = pytest.mark.gpu
+
+
+class ThreadTransport:
+    """Collectives between handles that live in threads of ONE process (device memory on one GPU)."""
+
+    def __init__(self, world):
+        self.world = world
+        self.bar = threading.Barrier(world, timeout=30)
+        self.slots = [None] * world
+
+    def callbacks(self, rank):
+        import torch
+        dev = torch.device("cuda", 0)
+        typ = {capi.DT_I32: "<i4", capi.DT_I64: "<i8", capi.DT_F64: "<f8"}
+
+        def all_reduce(buf, count, dtype, stream):
+            try:
+                torch.cuda.set_device(0)
+                torch.cuda.synchronize()
+                t = torch.as_tensor(_DevArray(buf, (int(count),), typ[dtype]), device=dev)
+                self.slots[rank] = t.clone()
+                self.bar.wait()
+                tot = self.slots[0].clone()
+                for r in range(1, self.world):          # fixed order: identical sums on every rank
+                    tot += self.slots[r]
+                self.bar.wait()
+                t.copy_(tot)
+                torch.cuda.synchronize()
+                return 0
+            except Exception:   # noqa: BLE001
+                return 1
+
+        def all_gather(send, recv, nbytes, stream):
+            try:
+                torch.cuda.set_device(0)
+                torch.cuda.synchronize()
+                nbytes = int(nbytes)
+                s = torch.as_tensor(_DevArray(send, (nbytes,), "|u1"), device=dev)
+                self.slots[rank] = s.clone()
+                self.bar.wait()
+                out = torch.as_tensor(_DevArray(recv, (self.world * nbytes,), "|u1"), device=dev)
+                for r in range(self.world):
+                    out[r * nbytes:(r + 1) * nbytes].copy_(self.slots[r])
+                torch.cuda.synchronize()
+                self.bar.wait()
+                return 0
+            except Exception:   # noqa: BLE001
+                return 1
+
+        return all_reduce, all_gather
+
+
+def _params(cost=capi.COST_P2PL, fixed=0, xicp=1):
+    if cost == capi.COST_P2PL:
+        p = capi.shipped_params()
+        p.use_xicp = xicp
+    else:
+        p = capi.default_params()
+        p.cost = capi.COST_GICP
+        p.use_trimmed = 0
+        p.max_dist = 0.5
+    p.fixed_iters = fixed
+    return p
+
+
+def _single(sc, p, T_init):
+    reg = capi.Registration(p)
+    if p.cost == capi.COST_P2PL:
+        reg.set_target(sc.tgt_xyz, sc.tgt_nrm)
+        reg.set_source(sc.src_xyz, sc.src_nrm)
+    else:
+        reg.set_target(sc.tgt_xyz, None, sc.tgt_cov)
+        reg.set_source(sc.src_xyz, None, sc.src_cov)
+    T, res = reg.register(T_init)
+    out = (T, res.iterations, res.n_inliers, res.fitness, list(res.localizable))
+    reg.close()
+    return out
+
+
+def _two_ranks(sc, p, T_init, split, n_registrations=1):
+    world = 2
+    tr = ThreadTransport(world)
+    bounds = [0, int(split * sc.src_xyz.shape[0]), sc.src_xyz.shape[0]]
+    results, errors = [None] * world, [None] * world
+
+    def rank_main(rank):
+        try:
+            import torch
+            torch.cuda.set_device(0)
+            lo, hi = bounds[rank], bounds[rank + 1]
+            reg = capi.Registration(p)
+            if p.cost == capi.COST_P2PL:
+                reg.set_target(sc.tgt_xyz, sc.tgt_nrm)
+            else:
+                reg.set_target(sc.tgt_xyz, None, sc.tgt_cov)
+            ar, ag = tr.callbacks(rank)
+            reg.dist_init_custom(ar, ag, rank, world)
+            out = []
+            for _ in range(n_registrations):
+                if p.cost == capi.COST_P2PL:
+                    reg.set_source(sc.src_xyz[lo:hi], sc.src_nrm[lo:hi])
+                else:
+                    reg.set_source(sc.src_xyz[lo:hi], None, sc.src_cov[lo:hi])
+                T, res = reg.dist_register(T_init)
+                out.append((T, res.iterations, res.n_inliers, res.fitness, list(res.localizable), reg.dist_info()))
+            results[rank] = out
+            reg.dist_shutdown()
+            reg.close()
+        except Exception as e:   # noqa: BLE001
+            errors[rank] = e
+            tr.bar.abort()
+
+    ths = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(120)
+    assert errors == [None] * world, errors
+    return results
+
+
+@pytest.mark.parametrize("fixed,split", [(0, 0.5), (14, 0.37)])
+def test_two_ranks_one_gpu_c_abi_loop_equals_single_handle(fixed, split):
+    sc = synth.make_scene(24000, 240000, seed=91)
+    p = _params(fixed=fixed)
+    T_init = np.eye(4, dtype=np.float32)
+    T_init[:3, 3] = (0.01, -0.02, 0.0)
+    T1, it1, inl1, fit1, loc1 = _single(sc, p, T_init)
+    res = _two_ranks(sc, p, T_init, split, n_registrations=2)
+    for reg_idx in range(2):
+        Ta, ita, inla, fita, loca, infoa = res[0][reg_idx]
+        Tb, itb, inlb, fitb, locb, infob = res[1][reg_idx]
+        assert np.array_equal(Ta, Tb), "ranks disagree"
+        assert ita == itb == it1 and inla == inlb == inl1
+        assert loca == locb == loc1
+        dt, dr = synth.pose_error(Ta, T1)
+        assert dt <= 1e-6 and dr <= 1e-6, (dt, dr)
+        assert abs(fita - fit1) < 1e-12 and infoa["n_global"] == sc.src_xyz.shape[0]
+        assert infoa == infob
+        assert infoa["n_fused"] > 0, "the settled tail must run fused (one all-gather per iteration)"
+
+
+def test_two_ranks_one_gpu_gicp():
+    sc = synth.make_scene(12000, 120000, seed=92)
+    p = _params(cost=capi.COST_GICP, fixed=10)
+    T1, it1, inl1, _, _ = _single(sc, p, np.eye(4))
+    res = _two_ranks(sc, p, np.eye(4), 0.5)
+    Ta, ita, inla = res[0][0][:3]
+    Tb = res[1][0][0]
+    assert np.array_equal(Ta, Tb) and ita == it1 and inla == inl1
+    dt, dr = synth.pose_error(Ta, T1)
+    assert dt <= 1e-5 and dr <= 1e-5, (dt, dr)
+
+
+def test_one_rank_real_rccl_communicator():
+    """ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclAllGather through the library, world size 1 (the box has
+    one GPU; RCCL refuses two ranks on one device).  The loop is the N > 1 loop, collectives included."""
+    sc = synth.make_scene(20000, 200000, seed=93)
+    p = _params(fixed=12)
+    T1, it1, inl1, fit1, _ = _single(sc, p, np.eye(4))
+    reg = capi.Registration(p)
+    reg.set_target(sc.tgt_xyz, sc.tgt_nrm)
+    reg.set_source(sc.src_xyz, sc.src_nrm)
+    reg.dist_init(capi.dist_unique_id(), 0, 1)
+    with pytest.raises(capi.RegError):
+        reg.dist_init(capi.dist_unique_id(), 0, 1)        # already in a group
+    T, res = reg.dist_register(np.eye(4))
+    assert res.iterations == it1 and res.n_inliers == inl1
+    dt, dr = synth.pose_error(T, T1)
+    assert dt <= 1e-6 and dr <= 1e-6
+    reg.dist_shutdown()
+    T2, _ = reg.register(np.eye(4))                       # the handle is a plain single-GPU handle again
+    assert np.array_equal(T2, T1)
+    reg.close()
+
+
+def test_failing_transport_returns_an_error_instead_of_hanging():
+    sc = synth.make_scene(4000, 40000, seed=94)
+    reg = capi.Registration(_params(fixed=5))
+    reg.set_target(sc.tgt_xyz, sc.tgt_nrm)
+    reg.set_source(sc.src_xyz, sc.src_nrm)
+    reg.dist_init_custom(lambda *a: 1, lambda *a: 1, 0, 2)     # "peer" never answers: every collective fails
+    with pytest.raises(capi.RegError) as e:
+        reg.dist_register(np.eye(4))
+    assert e.value.status == 8      # REG_DEVICE_ERROR
+    reg.dist_shutdown()
+    reg.close()
+    with pytest.raises(capi.RegError) as e:
+        capi.Registration(_params()).dist_register(np.eye(4))
+    assert e.value.status == 5      # REG_NOT_CONFIGURED: reg_dist_init first
