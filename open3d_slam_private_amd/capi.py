@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "lib", "libo3dslam_reg.so")
+_SO = os.environ.get("O3D_REG_LIB") or os.path.join(_HERE, "lib", "libo3dslam_reg.so")   # O3D_REG_LIB: A/B builds (tools/)
 
 STATUS_NAMES = {0: "OK", 1: "EMPTY_TARGET", 2: "EMPTY_SOURCE", 3: "NO_CORRESPONDENCES", 4: "BAD_TRANSFORM",
                 5: "NOT_CONFIGURED", 6: "BAD_ARGUMENT", 7: "MISSING_FIELD", 8: "DEVICE_ERROR", 9: "UNSUPPORTED"}

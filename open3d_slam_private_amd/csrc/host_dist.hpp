@@ -313,7 +313,7 @@ reg_status reg_dist_phase(reg_handle* h, int phase) {
                 k_linearize_p2pl<<<h->n_blocks, 256, 0, h->stream>>>(
                     h->s_xyz.as<float4>(), h->has_snrm ? h->s_nrm.as<float4>() : nullptr, h->n, it, h->i_pos.as<int>(),
                     h->i_d2.as<float>(), h->t_pts.as<float4>(), h->t_nrm.as<float4>(), f, st, hist0 + 4096, hist0 + 2048,
-                    h->shift0, h->prm.use_xicp ? h->i_w.as<float>() : nullptr, h->i_partials.as<double>());
+                    h->shift0, h->prm.use_xicp ? h->i_w.as<float>() : nullptr, h->i_partials.as<double>(), h->i_cache.as<float4>());
             } else {
                 k_linearize_gicp<<<h->n_blocks, 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->s_cov.as<float4>(), h->n, it,
                                                                      h->i_pos.as<int>(), h->i_d2.as<float>(),
@@ -336,12 +336,26 @@ reg_status reg_dist_phase(reg_handle* h, int phase) {
             if (h->prm.cost != REG_COST_P2PL || h->dist_ranks <= 0) return REG_BAD_ARGUMENT;
             const FilterCfg f = make_filter_cfg(h, 0);
             uint8_t* hint = h->dbg.match_variant == 2 ? nullptr : h->i_hint.as<uint8_t>();
-            const int blocks = grid_for(h->n * 8);
             float* contrib = h->d_contrib.as<float>();
-            k_iter_fused<8><<<8 * ((blocks + 7) / 8), 256, 0, h->stream>>>(
-                h->s_xyz.as<float4>(), h->has_snrm ? h->s_nrm.as<float4>() : nullptr, h->n, h->i_iter.as<IterState>(),
-                h->grid, h->t_nrm.as<float4>(), f, h->i_pos.as<int>(), h->i_d2.as<float>(), h->i_w.as<float>(), hint,
-                contrib + kContribHdr, kContribCap, h->i_acc.as<double>(), blocks);
+            if (h->dbg.debug_flags & 16) {
+                const int blocks = grid_for(h->n * 8);
+                k_iter_fused<8><<<8 * ((blocks + 7) / 8), 256, 0, h->stream>>>(
+                    h->s_xyz.as<float4>(), h->has_snrm ? h->s_nrm.as<float4>() : nullptr, h->n, h->i_iter.as<IterState>(),
+                    h->grid, h->t_nrm.as<float4>(), f, h->i_pos.as<int>(), h->i_d2.as<float>(), h->i_w.as<float>(), hint,
+                    contrib + kContribHdr, kContribCap, h->i_acc.as<double>(), blocks);
+            } else {
+                const int blocks = grid_for(h->n);
+                k_coh_check<<<8 * ((blocks + 7) / 8), 256, 0, h->stream>>>(
+                    h->s_xyz.as<float4>(), h->has_snrm ? h->s_nrm.as<float4>() : nullptr, h->n, h->i_iter.as<IterState>(),
+                    h->grid, h->t_nrm.as<float4>(), f, h->i_pos.as<int>(), h->i_d2.as<float>(), h->i_w.as<float>(),
+                    h->i_cache.as<float4>(), h->i_queue.as<uint32_t>(), coherent_queue_cap(h->n), contrib + kContribHdr,
+                    kContribCap, h->i_acc.as<double>(), blocks);
+                k_coh_search<8><<<coherent_search_grid(h), 256, 0, h->stream>>>(
+                    h->s_xyz.as<float4>(), h->has_snrm ? h->s_nrm.as<float4>() : nullptr, h->n, h->i_iter.as<IterState>(),
+                    h->grid, h->t_nrm.as<float4>(), f, h->i_pos.as<int>(), h->i_d2.as<float>(), h->i_w.as<float>(), hint,
+                    h->i_cache.as<float4>(), h->i_queue.as<uint32_t>(), coherent_queue_cap(h->n), contrib + kContribHdr,
+                    kContribCap, h->i_acc.as<double>(), coherent_slack(h), (CohStats*)nullptr);
+            }
             k_pack_contrib<<<1, 64, 0, h->stream>>>(h->i_acc.as<double>(), it, contrib);
             h->have_match = true;
             break;
@@ -374,7 +388,7 @@ reg_status reg_dist_phase(reg_handle* h, int phase) {
             k_linearize_p2pl<<<h->n_blocks, 256, 0, h->stream>>>(
                 h->s_xyz.as<float4>(), h->has_snrm ? h->s_nrm.as<float4>() : nullptr, h->n, it, h->i_pos.as<int>(),
                 h->i_d2.as<float>(), h->t_pts.as<float4>(), h->t_nrm.as<float4>(), f, st, hist0 + 4096, hist0 + 2048,
-                h->shift0, h->prm.use_xicp ? h->i_w.as<float>() : nullptr, h->i_partials.as<double>());
+                h->shift0, h->prm.use_xicp ? h->i_w.as<float>() : nullptr, h->i_partials.as<double>(), h->i_cache.as<float4>());
             k_partials_sum<<<1, 1024, 0, h->stream>>>(h->i_partials.as<double>(), h->n_blocks, h->i_sums.as<double>(), it);
             break;
         }

@@ -90,7 +90,8 @@ static reg_status prepare_rowmajor(reg_handle* h, const float* T_init_row, const
     k_prepare_source<<<grid_for(n), 256, 0, h->stream>>>(
         h->s_raw.as<float>(), h->s_stride, (p2pl && h->has_snrm) ? h->s_nrm_raw.as<float>() : nullptr, h->s_nstride, n, pa,
         p2pl ? 1 : 0, h->perm, h->s_xyz.as<float4>(), (p2pl && h->has_snrm) ? h->s_nrm.as<float4>() : nullptr,
-        h->i_hint.as<uint8_t>(), h->i_hist.as<uint32_t>(), h->i_acc.as<double>(), kAccRows * kSums, si);
+        h->i_hint.as<uint8_t>(), h->i_hist.as<uint32_t>(), h->i_acc.as<double>(), kAccRows * kSums, si,
+        h->i_cache.as<float4>());
     if (!p2pl)
         k_pack_cov<<<grid_for(n), 256, 0, h->stream>>>(h->s_cov_raw.as<float>(), n, h->perm, h->s_cov.as<float4>());
     pmark("prepare_source");
@@ -129,6 +130,7 @@ static reg_status build_iter_state(reg_handle* h, const float* T_row, int update
     st->use_trim = (h->prm.cost == REG_COST_P2PL && h->prm.use_trimmed) ? 1 : 0;
     st->trim_ratio = h->prm.trim_ratio;
     st->band_cap = kBandCap;
+    st->qcount = h->i_qcount.as<unsigned int>();
     st->debug_narrow_band = ((h->dbg.debug_flags & 8) ? 1 : 0) | ((h->dbg.debug_flags & 64) ? 2 : 0);   // bit 1: no direct band ranking
     h->xicp_pending = false;
     for (int k = 0; k < 6; ++k) st->xicp_flags[k] = 1;
@@ -210,7 +212,8 @@ static reg_status enqueue_match(reg_handle* h, bool zero_hist = false) {
         const dim3 grid(8 * ((blocks + 7) / 8)), block(256);
         auto go = [&](auto kernel) {
             launch_timed(h, 0, kernel, grid, block, (const float4*)h->s_xyz.as<float4>(), h->n, it, h->grid,
-                         h->i_pos.as<int>(), h->i_d2.as<float>(), hist0, hist2, hint, h->shift0, h->dbg.debug_flags, blocks);
+                         h->i_pos.as<int>(), h->i_d2.as<float>(), hist0, hist2, hint, h->shift0, h->dbg.debug_flags, blocks,
+                         h->i_cache.as<float4>());
         };
         if (lanes == 4)
             go(k_match_g8<4>);
@@ -250,7 +253,7 @@ static reg_status enqueue_linearize(reg_handle* h, bool want_w, bool limit_from_
             h->s_xyz.as<float4>(), h->has_snrm ? h->s_nrm.as<float4>() : nullptr, h->n, it, h->i_pos.as<int>(),
             h->i_d2.as<float>(), h->t_pts.as<float4>(), h->t_nrm.as<float4>(), f, h->i_state.as<SelectState>(),
             h->i_hist.as<uint32_t>() + 4096, h->i_hist.as<uint32_t>() + 2048, h->shift0, w,
-            h->i_partials.as<double>());
+            h->i_partials.as<double>(), h->i_cache.as<float4>());
     } else {
         k_linearize_gicp<<<h->n_blocks, 256, 0, h->stream>>>(h->s_xyz.as<float4>(), h->s_cov.as<float4>(), h->n, it,
                                                              h->i_pos.as<int>(), h->i_d2.as<float>(),
@@ -291,13 +294,37 @@ static FilterCfg make_filter_cfg(const reg_handle* h, int trim_mode) {
 
 // Fused iteration (point-to-plane): search + weights + normal equations in one kernel, band resolution +
 // solve + update in the second.  Two launches per Gauss-Newton iteration.
+// slack of the candidate-bounded boxes in the coherent kernel's fallback searches: a quarter bin (see nearest_group)
+static inline float coherent_slack(const reg_handle* h) { return 0.25f * h->info.cell_size; }
+// k_coh_search: a fixed grid that strides over the queue (32 points per workgroup and pass): enough workgroups for the
+// usual few per cent of the reading in one pass, never more than the reading needs
+static inline int coherent_search_grid(const reg_handle* h) { return (int)std::min<int64_t>(1024, (h->n + 31) / 32); }
+// capacity of one of the kQueues sub-queues: workgroup lb (256 points) appends to sub-queue lb % kQueues
+static inline int coherent_queue_cap(int64_t n) { return (int)(((n + 255) / 256 + kQueues - 1) / kQueues) * 256; }
+
 template <int G>
 static void launch_fused(reg_handle* h, const FilterCfg& f, float* w, uint8_t* hint) {
-    const int blocks = grid_for(h->n * G);
-    launch_timed(h, 1, k_iter_fused<G>, dim3(8 * ((blocks + 7) / 8)), dim3(256), (const float4*)h->s_xyz.as<float4>(),
-                 (const float4*)(h->has_snrm ? h->s_nrm.as<float4>() : nullptr), h->n, h->i_iter.as<IterState>(), h->grid,
-                 (const float4*)h->t_nrm.as<float4>(), f, h->i_pos.as<int>(), h->i_d2.as<float>(), w, hint,
-                 h->i_band.as<float>(), (int)kBandCap, h->i_acc.as<double>(), blocks);
+    int blocks;
+    if (h->dbg.debug_flags & 16) {   // A/B switch: the fused kernel without the temporal-coherence shortcut
+        blocks = grid_for(h->n * G);
+        launch_timed(h, 1, k_iter_fused<G>, dim3(8 * ((blocks + 7) / 8)), dim3(256), (const float4*)h->s_xyz.as<float4>(),
+                     (const float4*)(h->has_snrm ? h->s_nrm.as<float4>() : nullptr), h->n, h->i_iter.as<IterState>(), h->grid,
+                     (const float4*)h->t_nrm.as<float4>(), f, h->i_pos.as<int>(), h->i_d2.as<float>(), w, hint,
+                     h->i_band.as<float>(), (int)kBandCap, h->i_acc.as<double>(), blocks);
+    } else {
+        blocks = grid_for(h->n);
+        launch_timed(h, 1, k_coh_check, dim3(8 * ((blocks + 7) / 8)), dim3(256), (const float4*)h->s_xyz.as<float4>(),
+                     (const float4*)(h->has_snrm ? h->s_nrm.as<float4>() : nullptr), h->n, h->i_iter.as<IterState>(), h->grid,
+                     (const float4*)h->t_nrm.as<float4>(), f, h->i_pos.as<int>(), h->i_d2.as<float>(), w,
+                     (const float4*)h->i_cache.as<float4>(), h->i_queue.as<uint32_t>(), coherent_queue_cap(h->n),
+                     h->i_band.as<float>(), (int)kBandCap, h->i_acc.as<double>(), blocks);
+        launch_timed(h, 2, k_coh_search<G>, dim3(coherent_search_grid(h)), dim3(256), (const float4*)h->s_xyz.as<float4>(),
+                     (const float4*)(h->has_snrm ? h->s_nrm.as<float4>() : nullptr), h->n, h->i_iter.as<IterState>(), h->grid,
+                     (const float4*)h->t_nrm.as<float4>(), f, h->i_pos.as<int>(), h->i_d2.as<float>(), w, hint,
+                     h->i_cache.as<float4>(), (const uint32_t*)h->i_queue.as<uint32_t>(), coherent_queue_cap(h->n),
+                     h->i_band.as<float>(), (int)kBandCap, h->i_acc.as<double>(), coherent_slack(h),
+                     h->env.coh_stats ? h->i_stats.as<CohStats>() : (CohStats*)nullptr);
+    }
     ++h->seq;
     k_reduce_update<<<1, 1024, 0, h->stream>>>(h->i_acc.as<double>(), blocks, h->i_iter.as<IterState>(), h->d_mirror,
                                                h->seq, 1, h->i_band.as<float>(), w, nullptr, nullptr, 0, 0, nullptr);
@@ -585,6 +612,14 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
             fprintf(stderr, "):");
             for (int l = 0; l <= h->grid.n_levels; ++l) fprintf(stderr, " %lld", cnt[l]);
             fprintf(stderr, "\n");
+        }
+    }
+    if (h->env.coh_stats) {
+        CohStats cs;
+        if (hipMemcpy(&cs, h->i_stats.p, sizeof(cs), hipMemcpyDeviceToHost) == hipSuccess) {
+            fprintf(stderr, "[o3dreg] coherent fused iterations: %llu point-iterations, %llu searched (%.2f %%)\n", cs.n_points,
+                    cs.n_searched, cs.n_points ? 100.0 * (double)cs.n_searched / (double)cs.n_points : 0.0);
+            (void)hipMemset(h->i_stats.p, 0, sizeof(cs));
         }
     }
     if (h->env.stamps) {

@@ -38,6 +38,7 @@ struct EnvSwitches {
     bool no_burst = false;      // O3D_NO_BURST: trickle-feed the fused iterations (A/B of the burst submission)
     bool hints = false;         // O3D_HINTS: histogram of the terminating search level of the last iteration
     bool stamps = false;        // O3D_STAMPS: in-kernel cycle stamps of the update kernel
+    bool coh_stats = false;     // O3D_COH_STATS: share of the reading points the coherent fused kernel had to search
     int lookahead = 2;          // O3D_KAHEAD
     float settle_tol = 0.25f;   // O3D_SETTLE
     float halo_ratio = 1.5f;    // O3D_HALO_RATIO: halo-bin edge in units of the brick-table bin edge (tuning sweeps)
@@ -49,6 +50,7 @@ struct EnvSwitches {
         no_burst = getenv("O3D_NO_BURST") != nullptr;
         hints = getenv("O3D_HINTS") != nullptr;
         stamps = getenv("O3D_STAMPS") != nullptr;
+        coh_stats = getenv("O3D_COH_STATS") != nullptr;
         if (const char* v = getenv("O3D_KAHEAD")) lookahead = std::max(1, atoi(v));
         if (const char* v = getenv("O3D_SETTLE")) settle_tol = (float)atof(v);
         if (const char* v = getenv("O3D_HALO_RATIO")) halo_ratio = std::min(4.0f, std::max(0.5f, (float)atof(v)));
@@ -91,7 +93,7 @@ struct reg_handle {
     bool has_tnrm = false, has_tcov = false;
     float c_ref[3] = {0, 0, 0};
     DevBuf t_raw, t_nrm_raw, t_cov_raw, t_centred, t_keys, t_keys2, t_vals, t_vals2, t_pts, t_nrm, t_cov, t_flags,
-        t_scan, t_hash, t_cells, t_tmp, t_misc, t_dir;
+        t_scan, t_hash, t_cells, t_tmp, t_misc, t_dir, t_rows;
     Grid grid;
     reg_target_info info;
     float target_build_ms = 0.f;
@@ -111,7 +113,7 @@ struct reg_handle {
     IterState* h_iter = nullptr;      // pinned staging copy of the iteration state
     DevBuf i_iter;                    // IterState on the device
     unsigned long long seq = 0;
-    DevBuf t_halo_start, t_halo_cursor, t_halo_pts, i_band, i_acc;
+    DevBuf t_halo_start, t_halo_cursor, t_halo_pts, i_band, i_acc, i_cache, i_stats, i_queue, i_qcount;
     DevBuf s_prep;
     PrepState* h_prep = nullptr;      // mapped pinned host copy of the device-side preparation state
     PrepState* d_prep_host = nullptr; // device view of h_prep
@@ -255,9 +257,9 @@ void reg_destroy(reg_handle* h) {
     h->n_mom.release();
     DevBuf* bufs[] = {&h->t_raw, &h->t_nrm_raw, &h->t_cov_raw, &h->t_centred, &h->t_keys, &h->t_keys2, &h->t_vals,
                       &h->t_vals2, &h->t_pts, &h->t_nrm, &h->t_cov, &h->t_flags, &h->t_scan, &h->t_hash, &h->t_cells,
-                      &h->t_tmp, &h->t_misc, &h->t_dir, &h->s_raw, &h->s_nrm_raw, &h->s_cov_raw, &h->s_xyz, &h->s_nrm, &h->s_cov,
+                      &h->t_tmp, &h->t_misc, &h->t_dir, &h->t_rows, &h->s_raw, &h->s_nrm_raw, &h->s_cov_raw, &h->s_xyz, &h->s_nrm, &h->s_cov,
                       &h->s_misc, &h->i_pos, &h->i_d2, &h->i_w, &h->i_hist, &h->i_state, &h->i_partials, &h->i_sums,
-                      &h->i_ids, &h->d_contrib, &h->d_gathered, &h->s_prep, &h->i_iter, &h->t_halo_start, &h->t_halo_cursor, &h->t_halo_pts, &h->i_band, &h->i_acc, &h->i_hint, &h->s_keys, &h->s_keys2, &h->s_perm, &h->s_perm2, &h->s_tmp, &h->i_tmpf};
+                      &h->i_ids, &h->d_contrib, &h->d_gathered, &h->s_prep, &h->i_iter, &h->t_halo_start, &h->t_halo_cursor, &h->t_halo_pts, &h->i_band, &h->i_acc, &h->i_cache, &h->i_stats, &h->i_queue, &h->i_qcount, &h->i_hint, &h->s_keys, &h->s_keys2, &h->s_perm, &h->s_perm2, &h->s_tmp, &h->i_tmpf};
     for (DevBuf* b : bufs) b->release();
     if (h->h_mirror) (void)hipHostFree(h->h_mirror);
     if (h->h_iter) (void)hipHostFree(h->h_iter);
@@ -400,16 +402,29 @@ static reg_status build_grid(reg_handle* h, float c, const float bmin[3], const 
     const int bdx = (int)std::ceil(dims[0] / kBrickDim), bdy = (int)std::ceil(dims[1] / kBrickDim),
               bdz = (int)std::ceil(dims[2] / kBrickDim);
     const size_t n_dir = (size_t)bdx * bdy * bdz;
-    const bool use_dir = n_dir <= ((size_t)64 << 20) && !(h->dbg.debug_flags & 32);
+    // The group search needs the dense directory + row masks (12 bytes per brick coordinate): up to 256 M coordinates = 3 GB
+    // of a 288 GB device.  Beyond that the bin edge is too small for the extent of the cloud (reg_set_target enlarges an
+    // automatic edge and rejects an explicit one).
+    if (n_dir > ((size_t)256 << 20)) {
+        h->err = "cell_size too small for the target extent (more than 2^28 brick coordinates)";
+        return REG_UNSUPPORTED;
+    }
+    const bool use_dir = true, use_rows = true;
     if (use_dir) {
         HIPCHK(h, h->t_dir.reserve(n_dir * 4));
         HIPCHK(h, hipMemsetAsync(h->t_dir.p, 0xff, n_dir * 4, h->stream));
+        if (use_rows) {
+            HIPCHK(h, h->t_rows.reserve(n_dir * 8));
+            HIPCHK(h, hipMemsetAsync(h->t_rows.p, 0, n_dir * 8, h->stream));
+        }
     }
     k_fill_tables<<<grid_for(m), 256, 0, h->stream>>>(h->t_keys2.as<uint64_t>(), h->t_flags.as<uint32_t>(),
                                                        h->t_scan.as<uint32_t>(), m, h->t_hash.as<HashEntry>(), cap - 1,
                                                        h->t_cells.as<uint32_t>(), h->t_misc.as<uint32_t>(),
-                                                       use_dir ? h->t_dir.as<int32_t>() : nullptr, bdx, bdy);
+                                                       use_dir ? h->t_dir.as<int32_t>() : nullptr, bdx, bdy,
+                                                       use_rows ? h->t_rows.as<unsigned long long>() : nullptr);
     g.brick_dir = use_dir ? h->t_dir.as<int32_t>() : nullptr;
+    g.brick_rows = use_rows ? h->t_rows.as<unsigned long long>() : nullptr;
     g.bdx = bdx;
     g.bdy = bdy;
     g.bdz = bdz;
@@ -426,7 +441,7 @@ static reg_status build_grid(reg_handle* h, float c, const float bmin[3], const 
     g.cell_start = h->t_cells.as<uint32_t>();
     h->info.n_bricks = nb;
     h->info.n_cells_occupied = *occupied;
-    h->info.table_bytes = (int64_t)((size_t)cap * sizeof(HashEntry) + n_cells * 4 + (use_dir ? n_dir * 4 : 0));
+    h->info.table_bytes = (int64_t)((size_t)cap * sizeof(HashEntry) + n_cells * 4 + (use_dir ? n_dir * 4 : 0) + (use_rows ? n_dir * 8 : 0));
     h->info.cell_size = c;
     return REG_OK;
 }
@@ -625,6 +640,10 @@ static reg_status set_target_impl(reg_handle* h, const float* xyz, int64_t xyz_s
         cs = std::max(cs, cs_min);
         for (int pass = 0; pass < 3; ++pass) {
             reg_status s = build_grid(h, cs, bmin, bmax, &occupied);
+            for (int grow = 0; s == REG_UNSUPPORTED && grow < 8; ++grow) {   // extent / edge^3 beyond the dense directory
+                cs *= 1.3f;
+                s = build_grid(h, cs, bmin, bmax, &occupied);
+            }
             if (s != REG_OK) return s;
             const float per = (float)m / (float)std::max(1u, occupied);
             if (per <= 1.5f * occ && per >= 0.625f * occ) break;
@@ -1181,6 +1200,16 @@ reg_status reg_set_source(reg_handle* h, const float* xyz, int64_t xyz_stride, c
     HIPCHK(h, h->i_acc.reserve((size_t)kAccRows * kSums * 8));
     HIPCHK(h, h->i_sums.reserve(kSums * 8));
     HIPCHK(h, h->i_hint.reserve((size_t)n));
+    HIPCHK(h, h->i_cache.reserve((size_t)n * 48));   // per reading point: anchor + bound | matched point | its normal
+    HIPCHK(h, h->i_queue.reserve(((size_t)((n + 255) / 256 + 63) / 64) * 256 * 64 * 4));   // kQueues sub-queues (coherent_queue_cap)
+    if (!h->i_qcount.p) {
+        HIPCHK(h, h->i_qcount.reserve(64 * 16 * 4));
+        HIPCHK(h, hipMemsetAsync(h->i_qcount.p, 0, 64 * 16 * 4, h->stream));
+    }
+    if (!h->i_stats.p) {
+        HIPCHK(h, h->i_stats.reserve(256));
+        HIPCHK(h, hipMemsetAsync(h->i_stats.p, 0, 256, h->stream));
+    }
     h->s_stride = xyz_stride;
     h->s_nstride = nrm_stride;
     h->perm = nullptr;

@@ -133,7 +133,7 @@ __global__ void k_brick_heads(const uint64_t* __restrict__ keys, int64_t n, uint
 __global__ void k_fill_tables(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ flags,
                               const uint32_t* __restrict__ scan, int64_t n, HashEntry* hash, uint32_t mask,
                               uint32_t* __restrict__ counts, uint32_t* __restrict__ occupied,
-                              int32_t* __restrict__ dir, int bdx, int bdy) {
+                              int32_t* __restrict__ dir, int bdx, int bdy, unsigned long long* __restrict__ rows) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t bid = scan[i] - 1u;
@@ -159,6 +159,12 @@ __global__ void k_fill_tables(const uint64_t* __restrict__ keys, const uint32_t*
         }
     }
     const uint32_t old = atomicAdd(&counts[(size_t)bid * kBrickCells + local], 1u);
+    if (rows && old == 0) {   // first point of its bin: mark the bin's x-row (z_local * 8 + y_local) as occupied
+        const uint64_t bk = key >> (3 * kBrickLog2);
+        const uint32_t m18 = (1u << kBrickBits) - 1u;
+        const uint32_t bx = (uint32_t)bk & m18, by = (uint32_t)(bk >> kBrickBits) & m18, bz = (uint32_t)(bk >> (2 * kBrickBits)) & m18;
+        atomicOr(&rows[((size_t)bz * bdy + by) * bdx + bx], 1ull << (local >> kBrickLog2));
+    }
     // one aggregated atomic per wave on the single "occupied bins" word (same-address atomics serialise)
     const unsigned long long first = __ballot(old == 0);
     if (first && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)first) - 1)) atomicAdd(occupied, (uint32_t)__popcll(first));

@@ -244,6 +244,312 @@ k_iter_fused(const float4* __restrict__ src, const float4* __restrict__ src_nrm,
     }
 }
 
+// =================================================================================================
+// Fused iteration with temporal coherence (the settled tail of a registration)
+// =================================================================================================
+// Once the pose only moves by fractions of a millimetre per iteration, almost every reading point keeps its neighbour.
+// The searches of earlier iterations leave, per reading point, an ANCHOR (the transformed position the search ran at) and
+// a BOUND G2 = min(runner-up d2, covered radius^2): every reference point other than the winner was at least sqrt(G2)
+// away from the anchor.  At the new position p' (|p' - anchor| = delta) the triangle inequality gives, for every other
+// point x, dist(p', x) >= sqrt(G2) - delta; so if the old winner b satisfies dist(p', b) + delta < sqrt(G2) (with 1e-5
+// relative slack on each term, 30x the rounding of the fp32 expressions involved), b is still the UNIQUE nearest
+// neighbour under the fp32 comparison the full search would make, and its d2 -- evaluated with the same NC5 expression
+// -- is the value the full search would report.  Such a point costs ~100 bytes (reading point, anchor, previous match,
+// matched point and normal) instead of a halo run of ~35 candidate records; the others (a few per cent: runner-up nearly
+// as close as the winner, or the winner beyond the halo radius) are queued for k_coh_search, the full search, which
+// refreshes anchor and bound.  Results are identical to k_iter_fused by construction.
+//
+// Two launches, so that the searches -- which cluster in space (clutter, thin structures) and would pile up in a few
+// workgroups -- are spread evenly over the chip by the second one:
+//   k_coh_check   256 reading points per workgroup, one lane per point: shortcut test; weights, class, factor row
+//                 E = {F0..F5, r, 1 | kept, matched, kept d2, below-band} in LDS for the points that pass (zero row
+//                 otherwise); the 32 sums from the LDS table (thread t owns component t & 31 for the 32 rows of part
+//                 t >> 5); failed points are appended to a queue (one atomic per workgroup).
+//   k_coh_search  fixed grid, grid-stride over the queue in chunks of 32 points: nearest_group with G = 8 lanes per point,
+//                 then the same epilogue and a 32-row LDS table.
+constexpr int kCohRow = 13;   // 12 floats per factor row + 1 pad (bank spread)
+struct CohStats {
+    unsigned long long n_points, n_searched;
+};
+
+// A reading point whose d2 falls into the predicted band: its products go into a record the update kernel decides on
+// (out of line: a few hundred points per launch take this path, and its 32 live floats would otherwise set the register
+// budget of the whole kernel).
+__device__ __noinline__ void write_band_record(IterState* it, float* __restrict__ band, int band_cap, float3 p, float4 tq,
+                                               float4 nn, float w, float d2, int q) {
+    float vals[kSums];
+#pragma unroll
+    for (int k = 0; k < kSums; ++k) vals[k] = 0.f;
+    if (w != 0.f) {
+        p2pl_products(p, tq, nn, w, vals);
+        vals[28] = 1.f;
+        vals[30] = d2;
+    }
+    // one returning atomic per wave (the lanes that reach this point share it): same-address atomics serialise
+    const unsigned long long act = __ballot(true);
+    const int lane = (int)(threadIdx.x & 63), leader = __ffsll((long long)act) - 1;
+    unsigned base = 0;
+    if (lane == leader) base = atomicAdd(&it->band_count, (unsigned)__popcll(act));
+    base = (unsigned)__shfl((int)base, leader);
+    const unsigned slot = base + (unsigned)__popcll(act & ((1ull << lane) - 1ull));
+    if (slot < (unsigned)band_cap) {
+#pragma unroll
+        for (int k = 0; k < 31; ++k)
+            if (k != 29) band[band_at(k, slot)] = vals[k];
+        band[band_at(29, slot)] = d2;   // [29] = d2 (the "matched" count is added from the class)
+        band[band_at(31, slot)] = __int_as_float(q);
+    }
+}
+
+// Weights, class and factor row of ONE matched reading point (one lane); writes the outputs of the point.
+// row[0..5] = F, [6] = r, [7] = 1 (kept rows only), [8] kept, [9] matched, [10] kept d2, [11] below the band.
+__device__ __forceinline__ void coh_epilogue(const Xf& T, const FilterCfg& f, float band_lo, float band_hi, const float3 p,
+                                             int64_t q, int mpos, float md2, const float4 tq, const float4 nn,
+                                             const float4* __restrict__ src_nrm,
+                                             IterState* it, float* __restrict__ band, int band_cap, int* __restrict__ pos_io,
+                                             float* __restrict__ d2_out, float* __restrict__ w_out, float (&row)[12]) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) row[k] = 0.f;
+    float w = 0.f;
+    int cls = 2;   // 0: certainly kept, 1: band, 2: dropped / unmatched
+    if (mpos >= 0) {
+        w = 1.f;
+        if (f.use_maxdist && !(md2 <= f.outlier_max_d2)) w = 0.f;
+        if (f.use_normal) {
+            const float4 sn = src_nrm[q];
+            const float3 nr = normalize3(xf_rot(T, sn.x, sn.y, sn.z));
+            const float3 nt = normalize3(make_float3(nn.x, nn.y, nn.z));
+            float a = nr.x * nt.x;
+            float bb = nr.y * nt.y;
+            float val = a + bb;
+            a = nr.z * nt.z;
+            val = val + a;
+            if (val < f.cos_max_angle) w = 0.f;
+        }
+        cls = md2 < band_lo ? 0 : (md2 < band_hi ? 1 : 2);
+        row[9] = 1.f;                               // matched
+        if (cls == 0) row[11] = 1.f;                // below the band (rank bookkeeping is independent of w)
+        if (w != 0.f && cls == 0) {
+            // F = [p x n ; n], r = (p - q) . n  (the weight is 1: w * F_a * F_c == F_a * F_c exactly)
+            float a = p.y * nn.z, bq = p.z * nn.y;
+            row[0] = a - bq;
+            a = p.z * nn.x; bq = p.x * nn.z;
+            row[1] = a - bq;
+            a = p.x * nn.y; bq = p.y * nn.x;
+            row[2] = a - bq;
+            row[3] = nn.x; row[4] = nn.y; row[5] = nn.z;
+            const float dx = p.x - tq.x, dy = p.y - tq.y, dz = p.z - tq.z;
+            float r = dx * nn.x;
+            float t2 = dy * nn.y;
+            r = r + t2;
+            t2 = dz * nn.z;
+            r = r + t2;
+            row[6] = r;
+            row[7] = 1.f;
+            row[8] = 1.f;                           // kept
+            row[10] = md2;                          // kept d2
+        }
+        if (cls == 1) write_band_record(it, band, band_cap, p, tq, nn, w, md2, (int)q);   // decided by the update kernel
+    }
+    pos_io[q] = mpos;
+    d2_out[q] = mpos >= 0 ? md2 : INFINITY;
+    if (w_out) w_out[q] = (cls == 2) ? 0.f : w;   // band points: provisional, patched by the update kernel
+}
+
+// Component `comp` of the 32 sums over `rows` consecutive factor rows starting at E (fp32 product, fp64 sum).
+__device__ __forceinline__ double coh_component(const float* E, int rows, int comp) {
+    double acc = 0.0;
+    if (comp < 28) {
+        const int ia = kProdCode.a[comp] >> 2, ic = kProdCode.c[comp] >> 2;
+        for (int i = 0; i < rows; ++i) {
+            const float v = E[i * kCohRow + ia] * E[i * kCohRow + ic];
+            acc += (double)v;
+        }
+    } else {
+        const int ia = 8 + (comp - 28);
+        for (int i = 0; i < rows; ++i) acc += (double)E[i * kCohRow + ia];
+    }
+    return acc;
+}
+
+__global__ void __launch_bounds__(256)
+k_coh_check(const float4* __restrict__ src, const float4* __restrict__ src_nrm, int64_t n, IterState* __restrict__ it,
+            Grid g, const float4* __restrict__ tgt_nrm, FilterCfg f, int* __restrict__ pos_io, float* __restrict__ d2_out,
+            float* __restrict__ w_out, const float4* __restrict__ cache /* 3 x n: anchor | matched point | its normal */,
+            uint32_t* __restrict__ queue, int queue_cap, float* __restrict__ band, int band_cap, double* __restrict__ partials,
+            int n_blocks) {
+    __shared__ __attribute__((aligned(16))) float E[256 * kCohRow];
+    __shared__ int s_wave_cnt[4];
+    __shared__ unsigned s_base;
+    __shared__ double sh[4][kSums];
+    const int t = threadIdx.x;
+    const int lb = xcd_block(n_blocks);
+    const int64_t q = lb < n_blocks ? (int64_t)lb * 256 + t : n;
+    const int64_t qc = q < n ? q : n - 1;
+    // everything that does not depend on the state travels with the state's scalar loads (see k_iter_fused)
+    // The matched reference point and its normal travel with the reading point (the match persists, so they are kept in
+    // the per-point cache instead of being gathered from the 5 M-point arrays every iteration: a random 16-byte gather
+    // costs a whole 128-byte line, FETCH_SIZE calibration in profiles/): the shortcut path only STREAMS.
+    const float4 s = src[qc];
+    const float4 c = cache[qc];
+    const float4 tq = cache[(size_t)n + qc];
+    const float4 nn = cache[2 * (size_t)n + qc];
+    const int pprev = pos_io[qc];
+    const int st_done = it->done, st_stall = it->stall;
+    const Xf T = load_xf(it);
+    const float band_lo = it->band_lo, band_hi = it->band_hi;
+    unsigned int* const qcount = it->qcount;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) asm volatile("" ::"s"(T.m[k]));
+    asm volatile("" ::"s"(band_lo), "s"(band_hi));
+    asm volatile("" ::"v"(s.x), "v"(c.w), "v"(pprev), "v"(tq.x), "v"(nn.x));
+    if ((st_done | st_stall) != 0) return;
+    const float3 p = xf_point(T, s.x, s.y, s.z);
+    // ---- does the previous neighbour provably remain the nearest one?
+    bool pass = false;
+    float md2 = INFINITY;
+    if (q < n && c.w > 0.f && pprev >= 0 && nn.w == 1.f) {   // nn.w: matched point + normal of `pprev` are cached
+        const float dx = p.x - tq.x, dy = p.y - tq.y, dz = p.z - tq.z;
+        float a = dx * dx;
+        float b = dy * dy;
+        float d2 = a + b;
+        a = dz * dz;
+        d2 = d2 + a;                                   // NC5: the value the full search would compute for this pair
+        const float ex = p.x - c.x, ey = p.y - c.y, ez = p.z - c.z;
+        const float delta = __builtin_amdgcn_sqrtf(ex * ex + ey * ey + ez * ez);
+        const float lhs = (__builtin_amdgcn_sqrtf(d2) + delta) * 1.00001f + 1e-30f;
+        const float rhs = __builtin_amdgcn_sqrtf(c.w) * 0.99999f;
+        pass = d2 <= g.max_d2 && lhs < rhs;
+        md2 = d2;
+    }
+    const bool need = q < n && !pass;
+    // queue the points that need a search: wave ballot, one atomic per workgroup
+    const unsigned long long bal = __ballot(need);
+    const int lane = t & 63, wave = t >> 6;
+    if (lane == 0) s_wave_cnt[wave] = (int)__popcll(bal);
+    __syncthreads();
+    if (t == 0) {
+        const int tot = s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3];
+        s_base = tot ? atomicAdd(&qcount[(lb & (kQueues - 1)) * kQueueStride], (unsigned)tot) : 0u;
+    }
+    __syncthreads();
+    if (need) {
+        unsigned at = s_base + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+        for (int w2 = 0; w2 < wave; ++w2) at += (unsigned)s_wave_cnt[w2];
+        queue[(size_t)(lb & (kQueues - 1)) * queue_cap + at] = (uint32_t)q;   // at < queue_cap: host_loop.hpp sizes it
+    }
+    // ---- weights, class, factor row of the points that passed (zero row otherwise: k_coh_search accounts for those)
+    float row[12];
+    if (pass) {
+        coh_epilogue(T, f, band_lo, band_hi, p, q, pprev, md2, tq, nn, src_nrm, it, band, band_cap, pos_io, d2_out, w_out, row);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) row[k] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) E[t * kCohRow + k] = row[k];
+    __syncthreads();
+    // ---- the 32 sums of this workgroup's rows
+    const int comp = t & (kSums - 1), part = t >> 5;
+    double acc = coh_component(E + (part * 32) * kCohRow, 32, comp);
+    acc += __shfl_xor(acc, 32);                          // the two parts of a wave
+    if (lane < kSums) sh[wave][lane] = acc;
+    __syncthreads();
+    if (t < kSums && lb < n_blocks) {
+        const double tot = (sh[0][t] + sh[1][t]) + (sh[2][t] + sh[3][t]);
+        unsafeAtomicAdd(&partials[(size_t)(lb & (kAccRows - 1)) * kSums + t], tot);
+    }
+}
+
+template <int G>
+__global__ void __launch_bounds__(256, O3D_MATCH_WAVES)
+k_coh_search(const float4* __restrict__ src, const float4* __restrict__ src_nrm, int64_t n, IterState* __restrict__ it,
+             Grid g, const float4* __restrict__ tgt_nrm, FilterCfg f, int* __restrict__ pos_io, float* __restrict__ d2_out,
+             float* __restrict__ w_out, uint8_t* __restrict__ hint, float4* __restrict__ cache,
+             const uint32_t* __restrict__ queue, int queue_cap, float* __restrict__ band, int band_cap,
+             double* __restrict__ partials, float slack, CohStats* __restrict__ stats) {
+    constexpr int kQ = 256 / G;   // reading points per chunk
+    __shared__ __attribute__((aligned(16))) uint32_t seg_lds[kQ * kSegWords<G>];
+    __shared__ __attribute__((aligned(16))) float E[kQ * kCohRow];
+    __shared__ double sh[4][kSums];
+    __shared__ unsigned s_pre[kQueues + 1];   // exclusive prefix of the sub-queue counts
+    const int t = threadIdx.x;
+    const int st_done = it->done, st_stall = it->stall;
+    const Xf T = load_xf(it);
+    const float band_lo = it->band_lo, band_hi = it->band_hi;
+    const unsigned int* const qcount = it->qcount;
+    if ((st_done | st_stall) != 0) return;
+    if (t < 64) {
+        static_assert(kQueues == 64, "one lane per sub-queue");
+        const unsigned cnt = qcount[t * kQueueStride];
+        unsigned incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned v = (unsigned)__shfl_up((int)incl, o);
+            if (t >= o) incl += v;
+        }
+        s_pre[t + 1] = incl;
+        if (t == 0) s_pre[0] = 0u;
+    }
+    __syncthreads();
+    const unsigned count = s_pre[kQueues];
+    if ((unsigned)blockIdx.x * kQ >= count) return;      // workgroup-uniform: nothing queued for this workgroup
+    const int sub = t & (G - 1), grp = t / G;
+    const int comp = t & (kSums - 1), part = t >> 5;     // 8 parts x (kQ / 8) rows
+    double acc = 0.0;
+    for (unsigned base = (unsigned)blockIdx.x * kQ; base < count; base += gridDim.x * kQ) {
+        const unsigned slot = base + (unsigned)grp;
+        float row[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) row[k] = 0.f;
+        if (slot < count) {
+            int sq = 0;   // sub-queue holding global slot `slot`: largest sq with s_pre[sq] <= slot
+#pragma unroll
+            for (int step = kQueues / 2; step >= 1; step >>= 1)
+                if (s_pre[sq + step] <= slot) sq += step;
+            const int64_t qq = (int64_t)queue[(size_t)sq * queue_cap + (slot - s_pre[sq])];
+            const float4 s2 = src[qq];
+            const int hv = hint ? (int)hint[qq] : 0;
+            const float3 p2 = xf_point(T, s2.x, s2.y, s2.z);
+            int lvl;
+            float cov2;
+            const Best bb = nearest_group<G>(g, p2, sub, -1, &lvl, seg_lds + grp * kSegWords<G>, hv >= 2 ? hv - 2 : -1, &cov2,
+                                             slack);
+            if (sub == 0) {
+                if (hint) hint[qq] = (uint8_t)(lvl + 1);
+                const int pc = bb.pos >= 0 ? bb.pos : 0;
+                const float4 tq = g.pts[pc];
+                float4 nn = tgt_nrm[pc];
+                nn.w = 1.f;
+                cache[qq] = make_float4(p2.x, p2.y, p2.z, bb.pos >= 0 ? fminf(bb.second, cov2) : -1.f);
+                cache[(size_t)n + qq] = tq;
+                cache[2 * (size_t)n + qq] = nn;
+                coh_epilogue(T, f, band_lo, band_hi, p2, qq, bb.pos, bb.d2, tq, nn, src_nrm, it, band, band_cap, pos_io, d2_out, w_out,
+                             row);
+            }
+        }
+        if (sub == 0) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) E[grp * kCohRow + k] = row[k];
+        }
+        __syncthreads();
+        acc += coh_component(E + (part * (kQ / 8)) * kCohRow, kQ / 8, comp);
+        __syncthreads();   // the table is rewritten by the next chunk
+    }
+    acc += __shfl_xor(acc, 32);
+    const int lane = t & 63, wave = t >> 6;
+    if (lane < kSums) sh[wave][lane] = acc;
+    __syncthreads();
+    if (t < kSums) {
+        const double tot = (sh[0][t] + sh[1][t]) + (sh[2][t] + sh[3][t]);
+        unsafeAtomicAdd(&partials[(size_t)(blockIdx.x & (kAccRows - 1)) * kSums + t], tot);
+    }
+    if (stats && t == 0 && blockIdx.x == 0) {
+        atomicAdd(&stats->n_points, (unsigned long long)n);
+        atomicAdd(&stats->n_searched, (unsigned long long)count);
+    }
+}
+
 // Block-wide (1024 threads): bin with cum[b] <= rank < cum[b+1] over h[0..nb), nb <= 2048 (2 bins per thread).
 __device__ __forceinline__ void block_pick1024(const uint32_t* h, int nb, uint32_t rank, uint32_t* wave_tot /*[16]*/,
                                                uint32_t* out /*[0]=bin, [1]=rank inside the bin*/) {

@@ -48,7 +48,8 @@ template <int G>
 __global__ void __launch_bounds__(256, O3D_MATCH_WAVES)
 k_match_g8(const float4* __restrict__ src, int64_t n, const IterState* __restrict__ it, Grid g, int* __restrict__ pos,
            float* __restrict__ d2, uint32_t* __restrict__ hist0 /* 2048 or null */,
-           uint32_t* __restrict__ hist2_to_zero, uint8_t* __restrict__ hint, int shift0, int debug, int n_blocks) {
+           uint32_t* __restrict__ hist2_to_zero, uint8_t* __restrict__ hint, int shift0, int debug, int n_blocks,
+           float4* __restrict__ cache /* anchor + bound for the temporal-coherence shortcut (k_iter_coherent), or null */) {
     __shared__ uint32_t sh[2048];
     __shared__ __attribute__((aligned(16))) uint32_t seg_lds[(256 / G) * kSegWords<G>];
     const int lb = xcd_block(n_blocks);
@@ -87,12 +88,14 @@ k_match_g8(const float4* __restrict__ src, int64_t n, const IterState* __restric
         // halo cannot answer, continue one regular level below that.
         const int hv = hint ? (int)hraw : 0;
         int lvl;
+        float cov2;
         const Best b = nearest_group<G, true>(g, p, sub, -1, &lvl, seg_lds + (threadIdx.x / G) * kSegWords<G>,
-                                        hv >= 2 ? hv - 2 : -1);
+                                        hv >= 2 ? hv - 2 : -1, &cov2);
         if (sub == 0) {
             pos[q] = b.pos;
             d2[q] = b.pos >= 0 ? b.d2 : INFINITY;
             if (hint) hint[q] = (uint8_t)(lvl + 1);
+            if (cache) cache[q] = make_float4(p.x, p.y, p.z, b.pos >= 0 ? fminf(b.second, cov2) : -1.f);
             if (hist0 && b.pos >= 0) atomicAdd(&sh[__float_as_uint(b.d2) >> shift0], 1u);
         }
     }
@@ -384,7 +387,8 @@ k_linearize_p2pl(const float4* __restrict__ src, const float4* __restrict__ src_
                  const int* __restrict__ pos, const float* __restrict__ d2, const float4* __restrict__ tgt,
                  const float4* __restrict__ tgt_nrm, FilterCfg f, SelectState* __restrict__ st,
                  const uint32_t* __restrict__ hist2, uint32_t* __restrict__ hist1_to_zero, int shift0,
-                 float* __restrict__ w_out, double* __restrict__ partials) {
+                 float* __restrict__ w_out, double* __restrict__ partials,
+                 float4* __restrict__ cache /* 3 x n (k_coh_check) or null: rows 1, 2 = matched point, its normal */) {
     // One batch for everything that does not depend on the match: match position, distance, reading point and normal
     // of this thread's point, the pose, the select state and this thread's 8 bins of the last radix level; then ONE
     // more batch for the matched point and its normal.  (It was a chain of six dependent round trips: done -> state ->
@@ -492,6 +496,10 @@ k_linearize_p2pl(const float4* __restrict__ src, const float4* __restrict__ src_
             }
         }
         if (w_out) w_out[i] = w;
+        if (cache && ps >= 0) {   // the pair this kernel has just gathered rides along with the reading point from now on
+            cache[(size_t)n + i] = q_ld;
+            cache[2 * (size_t)n + i] = make_float4(nn_ld.x, nn_ld.y, nn_ld.z, 1.f);
+        }
     }
     if (f.debug & 2) {
         double t = 0;

@@ -89,7 +89,8 @@ __global__ void k_prepare_source(const float* __restrict__ xyz, int64_t stride, 
                                  int64_t nrm_stride, int64_t n, PrepArgs pa, int centre,
                                  const uint32_t* __restrict__ perm, float4* __restrict__ out_xyz,
                                  float4* __restrict__ out_nrm, uint8_t* __restrict__ hint, uint32_t* __restrict__ hist,
-                                 double* __restrict__ acc, int n_acc, const StateInit si) {
+                                 double* __restrict__ acc, int n_acc, const StateInit si,
+                                 float4* __restrict__ cache) {
     float c[3], T0f[16];
     prep_compute(pa, c, T0f);
     if (blockIdx.x == 0) {
@@ -115,6 +116,7 @@ __global__ void k_prepare_source(const float* __restrict__ xyz, int64_t stride, 
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     hint[i] = 0;
+    if (cache) cache[i] = make_float4(0.f, 0.f, 0.f, -1.f);   // no anchor yet: the first search of the registration sets it
     // R3 (TransformationsImpl.cpp:73-76): a pre-transform whose rotation block is off by |1 - det| > 1e-3 moves the POINTS
     // with the re-orthogonalised copy; the normals and the composed result keep the matrix as given
     float T0c[16];

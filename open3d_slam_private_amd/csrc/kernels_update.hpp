@@ -432,6 +432,7 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
         __syncthreads();
     }
     if (threadIdx.x < kSums) sit->sums[threadIdx.x] = tot[threadIdx.x];
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + kQueues && sit->qcount) sit->qcount[(threadIdx.x - 64) * kQueueStride] = 0u;
     if (threadIdx.x >= 64) return;   // the rest is wave 0 only (wave-synchronous: no workgroup barriers below)
     const int lane = threadIdx.x;
     const unsigned long long st1 = __builtin_amdgcn_s_memtime();

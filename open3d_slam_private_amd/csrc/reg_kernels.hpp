@@ -56,6 +56,10 @@ struct Grid {
     // small enough to be stored densely (null otherwise).
     const int32_t* brick_dir;
     int bdx, bdy, bdz;
+    // Row occupancy per brick coordinate (same index as brick_dir; null without it): bit (z_local * 8 + y_local) is set
+    // when that x-row of 8 bins holds at least one point.  A bin box of a large radius is mostly empty rows (a surface
+    // crosses ~n of the n^2 rows of a brick): the wide level scan enumerates only the set bits.
+    const unsigned long long* brick_rows;
 };
 
 struct Xf {  // row-major 3x4
@@ -119,6 +123,7 @@ struct Best {
     float d2;
     uint32_t idx;  // original target index (tie-break: lowest wins)
     int pos;       // position in the sorted arrays
+    float second;  // smallest d2 among the scanned points at a DIFFERENT position (group search only; +inf: none)
 };
 
 // Scan every target point in bins [lo, hi] (inclusive, already clamped to the grid).
@@ -166,6 +171,7 @@ __device__ __forceinline__ Best nearest(const Grid& g, float3 p) {
     best.d2 = INFINITY;
     best.idx = 0xffffffffu;
     best.pos = -1;
+    best.second = INFINITY;
     for (int l = 0; l < g.n_levels; ++l) {
         const float rb = g.rho_box[l];
         // clamp in float before converting: handles +-inf radii and far-away queries
@@ -201,10 +207,15 @@ __device__ __forceinline__ void consider(const Grid& g, float3 p, const float4 t
     a = dz * dz;
     d2 = d2 + a;
     const uint32_t idx = __float_as_uint(t.w);
-    if (d2 <= g.max_d2 && (d2 < best.d2 || (d2 == best.d2 && idx < best.idx))) {
-        best.d2 = d2;
-        best.idx = idx;
-        best.pos = j;
+    if (d2 <= g.max_d2 && j != best.pos) {   // (the clamped tail of a flattened scan re-reads its last point)
+        if (d2 < best.d2 || (d2 == best.d2 && idx < best.idx)) {
+            best.second = best.d2;           // the previous best becomes the runner-up
+            best.d2 = d2;
+            best.idx = idx;
+            best.pos = j;
+        } else {
+            best.second = fminf(best.second, d2);
+        }
     }
 }
 
@@ -219,8 +230,18 @@ __device__ __forceinline__ void scan_run(const Grid& g, float3 p, uint32_t s, ui
     }
 }
 
+// Runner-up of the group: every lane offers the smallest d2 it has seen at a position other than the winner's.
+template <int G>
+__device__ __forceinline__ float group_second(const Best& mine, int winner_pos) {
+    float c = (mine.pos == winner_pos) ? mine.second : fminf(mine.d2, mine.second);
+#pragma unroll
+    for (int m = 1; m < G; m <<= 1) c = fminf(c, __shfl_xor(c, m));
+    return c;
+}
+
 template <int G>
 __device__ __forceinline__ Best group_min(Best b) {
+    const Best mine = b;
 #pragma unroll
     for (int m = 1; m < G; m <<= 1) {
         const float od2 = __shfl_xor(b.d2, m);
@@ -232,6 +253,7 @@ __device__ __forceinline__ Best group_min(Best b) {
             b.pos = opos;
         }
     }
+    b.second = group_second<G>(mine, b.pos);
     return b;
 }
 
@@ -245,18 +267,22 @@ __device__ __forceinline__ void consider_pos(const Grid& g, float3 p, const floa
     a = dz * dz;
     d2 = d2 + a;
     const int pos = (int)__float_as_uint(t.w);
-    if (d2 <= g.max_d2) {
+    if (d2 <= g.max_d2 && pos != best.pos) {
         if (d2 < best.d2) {
+            best.second = best.d2;
             best.d2 = d2;
             best.pos = pos;
             best.idx = 0xffffffffu;  // not fetched
-        } else if (d2 == best.d2 && pos != best.pos) {
+        } else if (d2 == best.d2) {
+            best.second = d2;        // an exact tie: the runner-up is as close as the winner
             if (best.idx == 0xffffffffu) best.idx = __float_as_uint(g.pts[best.pos].w);
             const uint32_t idx = __float_as_uint(g.pts[pos].w);
             if (idx < best.idx) {
                 best.idx = idx;
                 best.pos = pos;
             }
+        } else {
+            best.second = fminf(best.second, d2);
         }
     }
 }
@@ -273,11 +299,13 @@ __device__ __forceinline__ Best group_min_lazy(const Grid& g, Best b, int gbase)
     r.d2 = INFINITY;
     r.idx = 0xffffffffu;
     r.pos = -1;
+    r.second = INFINITY;
     if (mask == 0) return r;
     if ((mask & (mask - 1)) == 0) {  // exactly one lane holds the minimum
         r.d2 = m;
         r.pos = __shfl(b.pos, gbase + __ffs((int)mask) - 1);
         r.idx = (uint32_t)__shfl((int)b.idx, gbase + __ffs((int)mask) - 1);
+        r.second = group_second<G>(b, r.pos);
         return r;
     }
     // tie between lanes: lowest original index wins
@@ -290,6 +318,7 @@ __device__ __forceinline__ Best group_min_lazy(const Grid& g, Best b, int gbase)
     r.d2 = m;
     r.idx = mi;
     r.pos = __shfl(b.pos, gbase + __ffs((int)win) - 1);
+    r.second = group_second<G>(b, r.pos);
     return r;
 }
 
@@ -300,131 +329,207 @@ __device__ __forceinline__ Best group_min_lazy(const Grid& g, Best b, int gbase)
 // Large radii (first iterations of a registration) are bound by dependent-load rounds: this cuts them roughly in half.
 constexpr int kSegPerLane = 4;
 
+// index of the k-th (0-based) set bit of the 64-bit mask {lo, hi}; k < popcount
+__device__ __forceinline__ int nth_set_bit64(uint32_t lo, uint32_t hi, int k) {
+    int c = __popc(lo), base = 0;
+    uint32_t w = lo;
+    if (k >= c) { k -= c; w = hi; base = 32; }
+    c = __popc(w & 0xffffu);
+    if (k >= c) { k -= c; w >>= 16; base += 16; }
+    c = __popc(w & 0xffu);
+    if (k >= c) { k -= c; w >>= 8; base += 8; }
+    c = __popc(w & 0xfu);
+    if (k >= c) { k -= c; w >>= 4; base += 4; }
+    c = __popc(w & 0x3u);
+    if (k >= c) { k -= c; w >>= 2; base += 2; }
+    if (k >= (int)(w & 1u)) base += 1;
+    return base;
+}
+
+// Wide level scan, row-mask driven.  A box is cut into row segments (one per (brick, y, z): a contiguous run of sorted
+// points).  The bricks overlapping the bin box are taken G at a time (one brick per lane: directory entry and
+// row-occupancy mask arrive in ONE round trip); the set bits of the masks inside the box's (y, z) range are the
+// non-empty rows -- only those get a slot in the segment batches: every lane looks up kSegPerLane segments at once (bin
+// starts, independent loads), the non-empty ones are compacted into a per-group LDS list {first point, exclusive offset}
+// (`seg`: 2 * G * kSegPerLane + 2 words), and the group scans their concatenation in one flattened pass, each lane
+// walking the list monotonically.  A radius of 8 bins used to cost 17 x 17 x 3 = 867 row segments = 27 batches
+// of three dependent round trips each; a surface crossing the box leaves ~50 non-empty rows = 2 batches.
+// The scanned SET is unchanged (every point of every non-empty row inside the pruned box), hence the same exactness.
+// Returns the radius up to which every reference point is guaranteed to have been scanned (the level's rho, or -- when
+// the box was shrunk to a known candidate -- that candidate's distance plus `slack`).
 template <int G, bool kPrune>
-__device__ __forceinline__ void scan_level_wide(const Grid& g, const float3 p, int sub, int gbase, int l,
-                                                uint32_t* seg, Best& best) {
+__device__ __forceinline__ float scan_level_rows(const Grid& g, const float3 p, int sub, int gbase, int l,
+                                                 uint32_t* seg, Best& best, float slack) {
     constexpr int S = kSegPerLane, CAP = G * S;
     uint32_t* const seg_st = seg;         // [CAP]
     uint32_t* const seg_ex = seg + CAP;   // [CAP + 1]
     // Radius of the box: the level's rho_box, or -- when a candidate is already known (halo run, previous level) -- the
-    // candidate's own distance grown by the same margins: no point farther than the candidate can win, and every point
-    // at most as far (ties included) stays inside the box.
+    // candidate's own distance (+ slack) grown by the same margins: no point farther than the candidate can win, and
+    // every point at most as far (ties included) stays inside the box.
     float rb = g.rho_box[l];
-    if (best.pos >= 0 && g.rho[l] < INFINITY)
-        rb = fminf(rb, __builtin_amdgcn_sqrtf(best.d2) * 1.001f + (rb - g.rho[l]));
+    float cover = g.rho[l];
+    if (best.pos >= 0 && g.rho[l] < INFINITY) {
+        const float dc = __builtin_amdgcn_sqrtf(best.d2) + slack;
+        const float rs = dc * 1.001f + (rb - g.rho[l]);
+        if (rs < rb) {
+            rb = rs;
+            cover = dc;
+        }
+    }
     const int lox = (int)fminf(fmaxf(bin_coord_f(p.x - rb, g.ox, g.inv_c), 0.f), g.dimx - 1.f);
     const int loy = (int)fminf(fmaxf(bin_coord_f(p.y - rb, g.oy, g.inv_c), 0.f), g.dimy - 1.f);
     const int loz = (int)fminf(fmaxf(bin_coord_f(p.z - rb, g.oz, g.inv_c), 0.f), g.dimz - 1.f);
     const int hix = (int)fminf(fmaxf(bin_coord_f(p.x + rb, g.ox, g.inv_c), 0.f), g.dimx - 1.f);
     const int hiy = (int)fminf(fmaxf(bin_coord_f(p.y + rb, g.oy, g.inv_c), 0.f), g.dimy - 1.f);
     const int hiz = (int)fminf(fmaxf(bin_coord_f(p.z + rb, g.oz, g.inv_c), 0.f), g.dimz - 1.f);
-    const int ny = hiy - loy + 1, nz = hiz - loz + 1;
-    const int bx0 = lox >> kBrickLog2;
-    const int nbx = (hix >> kBrickLog2) - bx0 + 1;
-    const int nrow = nbx * ny;
-    const int total = nrow * nz;
+    const int bx0 = lox >> kBrickLog2, by0 = loy >> kBrickLog2, bz0 = loz >> kBrickLog2;
+    const int nbx = (hix >> kBrickLog2) - bx0 + 1, nby = (hiy >> kBrickLog2) - by0 + 1,
+              nbz = (hiz >> kBrickLog2) - bz0 + 1;
+    const int nbxy = nbx * nby;
+    const int n_bricks = nbxy * nbz;
     const unsigned gmask = (1u << G) - 1u;
     // Ball pruning (exact): a bin box holds ~2x the volume of the ball it covers.  Rows whose (y, z) bin interval lies
-    // farther than the box radius from the query are skipped and the others are cut to the x-range the ball reaches,
-    // in BIN units with a slack of kPruneSlack bins per axis: the bin coordinate fl(fl(v - o) * 1/c) of a reference point
-    // and of the query each carry a relative error of 2 * 2^-24, i.e. < 1e-3 bins below 8192 bins per axis -- the slack is
-    // twice their sum (larger grids: no pruning).  Every reference point within rho_box of the query stays
-    // inside the scanned set, which is all the termination test (best d2 <= rho^2 < rho_box^2) relies on.
+    // farther than the box radius from the query are skipped and the others are cut to the x-range the ball reaches, in BIN
+    // units with a slack of kPruneSlack bins per axis: the bin coordinate fl(fl(v - o) * 1/c) of a reference point and of
+    // the query each carry a relative error of 2 * 2^-24, i.e. < 1e-3 bins below 8192 bins per axis -- the slack is twice
+    // their sum (larger grids: no pruning).  Every reference point within rho_box of the query stays inside the scanned
+    // set, which is all the termination test (best d2 <= rho^2 < rho_box^2) relies on.
     constexpr float kPruneSlack = 4e-3f;
     const bool prune = kPrune && g.dimx <= 8192 && g.dimy <= 8192 && g.dimz <= 8192;
     const float fxq = (p.x - g.ox) * g.inv_c, fyq = (p.y - g.oy) * g.inv_c, fzq = (p.z - g.oz) * g.inv_c;
     const float rbb = rb * g.inv_c + kPruneSlack;
     const float rb2 = rbb * rbb;
-    for (int base = 0; base < total; base += CAP) {
-        // phase 1a: brick ids of this lane's segments (independent loads)
-        int bid[S], off[S];
+    for (int cb = 0; cb < n_bricks; cb += G) {
+        // ---- this lane's brick of the chunk: directory entry + row mask (one batch of independent loads)
+        const int bi = cb + sub;
+        int bid = -1;
+        uint32_t m_lo = 0, m_hi = 0;
+        if (bi < n_bricks) {
+            const int iz = bi / nbxy, rem = bi - iz * nbxy;
+            const int iy = rem / nbx, ix = rem - iy * nbx;
+            const int bx = bx0 + ix, by = by0 + iy, bz = bz0 + iz;
+            const size_t at = ((size_t)bz * g.bdy + by) * g.bdx + bx;
+            bid = g.brick_dir[at];
+            const unsigned long long rows = g.brick_rows[at];
+            // rows of this brick inside the box: y in [y0, y1], z in [z0, z1] (brick-local)
+            const int y0 = max(loy, by << kBrickLog2) & (kBrickDim - 1), y1 = min(hiy, (by << kBrickLog2) + kBrickDim - 1) & (kBrickDim - 1);
+            const int z0 = max(loz, bz << kBrickLog2) & (kBrickDim - 1), z1 = min(hiz, (bz << kBrickLog2) + kBrickDim - 1) & (kBrickDim - 1);
+            const unsigned long long ybits = (unsigned long long)(((1u << (y1 - y0 + 1)) - 1u) << y0);
+            const unsigned long long zhi = z1 == 7 ? ~0ull : ((1ull << (8 * (z1 + 1))) - 1ull);
+            const unsigned long long zsel = zhi & ~((1ull << (8 * z0)) - 1ull) & 0x0101010101010101ull;
+            const unsigned long long m = bid >= 0 ? (rows & (ybits * zsel)) : 0ull;
+            m_lo = (uint32_t)m;
+            m_hi = (uint32_t)(m >> 32);
+        }
+        // exclusive prefix of the row counts over the lanes of the group
+        const uint32_t cnt = (uint32_t)(__popc(m_lo) + __popc(m_hi));
+        uint32_t incl = cnt;
 #pragma unroll
-        for (int u = 0; u < S; ++u) {
-            const int t = base + u * G + sub;
-            bid[u] = -1;
-            off[u] = 0;
-            if (t < total) {
-                const int iz = t / nrow, rem = t - iz * nrow;
-                const int iy = rem / nbx, ix = rem - iy * nbx;
-                const int bx = bx0 + ix, cy = loy + iy, cz = loz + iz;
-                int gx0 = max(lox, bx << kBrickLog2), gx1 = min(hix, (bx << kBrickLog2) + kBrickDim - 1);
-                if (prune) {
-                    const float dyb = fmaxf(fmaxf((float)cy - fyq, fyq - (float)(cy + 1)) - kPruneSlack, 0.f);
-                    const float dzb = fmaxf(fmaxf((float)cz - fzq, fzq - (float)(cz + 1)) - kPruneSlack, 0.f);
-                    const float r2 = rb2 - dyb * dyb - dzb * dzb;
-                    if (r2 < 0.f) continue;   // the whole row lies outside the ball
-                    const float hxb = __builtin_amdgcn_sqrtf(r2) * 1.0001f + kPruneSlack;
-                    gx0 = max(gx0, (int)fminf(fmaxf(floorf(fxq - hxb), 0.f), g.dimx - 1.f));
-                    gx1 = min(gx1, (int)fminf(fmaxf(floorf(fxq + hxb), 0.f), g.dimx - 1.f));
-                    if (gx0 > gx1) continue;
+        for (int o = 1; o < G; o <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
+            if (sub >= o) incl += v;
+        }
+        const int total = (int)(uint32_t)__shfl((int)incl, gbase + G - 1);
+        if (total == 0) continue;
+        const uint32_t excl = incl - cnt;
+        for (int base = 0; base < total; base += CAP) {
+            // phase 1: this lane's row segments of the batch -> bin starts (independent loads)
+            uint32_t s[S], e[S];
+#pragma unroll
+            for (int u = 0; u < S; ++u) {
+                s[u] = 0;
+                e[u] = 0;
+                const int t = base + u * G + sub;
+                // owner lane of slot t (branch-free), then its mask / brick id by lane-indexed shuffles; lanes without a
+                // slot take part in the shuffles with a clamped slot
+                const int tc = min(t, total - 1);
+                int j = 0;   // = number of lanes whose inclusive prefix is <= tc (binary search over the group, by shuffles)
+#pragma unroll
+                for (int step = G / 2; step >= 1; step >>= 1) {
+                    const uint32_t v = (uint32_t)__shfl((int)incl, gbase + j + step - 1);
+                    if ((uint32_t)tc >= v) j += step;
                 }
-                bid[u] = brick_lookup(g, bx, cy >> kBrickLog2, cz >> kBrickLog2);
-                const int x0 = gx0 & (kBrickDim - 1), x1 = gx1 & (kBrickDim - 1);
-                off[u] = (((cz & (kBrickDim - 1)) << (2 * kBrickLog2)) | ((cy & (kBrickDim - 1)) << kBrickLog2)) |
-                         (x0 << 12) | (x1 << 16);
-            }
-        }
-        // phase 1b: bin starts (independent loads)
-        uint32_t s[S], e[S];
-#pragma unroll
-        for (int u = 0; u < S; ++u) {
-            s[u] = 0;
-            e[u] = 0;
-            if (bid[u] >= 0) {
-                const uint32_t* cs = g.cell_start + (size_t)bid[u] * kBrickCells + (off[u] & 0xfff);
-                s[u] = cs[(off[u] >> 12) & 15];
-                e[u] = cs[((off[u] >> 16) & 15) + 1];
-            }
-        }
-        // compact the non-empty segments into the group's LDS list, in segment order
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        uint32_t run_pts = 0, run_seg = 0;
-#pragma unroll
-        for (int u = 0; u < S; ++u) {
-            const uint32_t cnt = e[u] - s[u];
-            uint32_t incl = cnt;
-#pragma unroll
-            for (int o = 1; o < G; o <<= 1) {
-                const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
-                if (sub >= o) incl += v;
-            }
-            const uint32_t tot_u = (uint32_t)__shfl((int)incl, gbase + G - 1);
-            const unsigned m = (unsigned)(__ballot(cnt != 0) >> gbase) & gmask;
-            if (cnt != 0) {
-                const uint32_t my = run_seg + (uint32_t)__popc(m & ((1u << sub) - 1u));
-                seg_st[my] = s[u];
-                seg_ex[my] = run_pts + incl - cnt;
-            }
-            run_pts += tot_u;
-            run_seg += (uint32_t)__popc(m);
-        }
-        if (run_pts == 0) continue;
-        if (sub == 0) seg_ex[run_seg] = run_pts;   // sentinel: end of the last segment
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        // phase 2: flattened scan, 4 independent 16-byte loads in flight per lane
-        uint32_t k = 0, cur_ex = 0, cur_st = seg_st[0], next_ex = seg_ex[1];
-        constexpr int kUnroll = 4;
-        for (uint32_t f0 = 0; f0 < run_pts; f0 += kUnroll * G) {
-            float4 tv[kUnroll];
-            uint32_t jv[kUnroll];
-#pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
-                const uint32_t f = min(f0 + (uint32_t)(u * G + sub), run_pts - 1);   // clamp: duplicates are harmless
-                while (f >= next_ex) {
-                    ++k;
-                    cur_ex = next_ex;
-                    cur_st = seg_st[k];
-                    next_ex = seg_ex[k + 1];
+                const uint32_t o_lo = (uint32_t)__shfl((int)m_lo, gbase + j), o_hi = (uint32_t)__shfl((int)m_hi, gbase + j);
+                const int o_bid = __shfl(bid, gbase + j);
+                const uint32_t o_ex = (uint32_t)__shfl((int)excl, gbase + j);
+                if (t < total) {
+                    const int r = nth_set_bit64(o_lo, o_hi, (int)((uint32_t)tc - o_ex));   // row = z_local * 8 + y_local
+                    const int bj = cb + j;
+                    const int iz = bj / nbxy, rem = bj - iz * nbxy;
+                    const int iy = rem / nbx, ix = rem - iy * nbx;
+                    const int bx = bx0 + ix, cy = ((by0 + iy) << kBrickLog2) + (r & 7), cz = ((bz0 + iz) << kBrickLog2) + (r >> 3);
+                    int gx0 = max(lox, bx << kBrickLog2), gx1 = min(hix, (bx << kBrickLog2) + kBrickDim - 1);
+                    bool keep = true;
+                    if (prune) {
+                        const float dyb = fmaxf(fmaxf((float)cy - fyq, fyq - (float)(cy + 1)) - kPruneSlack, 0.f);
+                        const float dzb = fmaxf(fmaxf((float)cz - fzq, fzq - (float)(cz + 1)) - kPruneSlack, 0.f);
+                        const float r2 = rb2 - dyb * dyb - dzb * dzb;
+                        keep = !(r2 < 0.f);   // else: the whole row lies outside the ball
+                        if (keep) {
+                            const float hxb = __builtin_amdgcn_sqrtf(r2) * 1.0001f + kPruneSlack;
+                            gx0 = max(gx0, (int)fminf(fmaxf(floorf(fxq - hxb), 0.f), g.dimx - 1.f));
+                            gx1 = min(gx1, (int)fminf(fmaxf(floorf(fxq + hxb), 0.f), g.dimx - 1.f));
+                            keep = gx0 <= gx1;
+                        }
+                    }
+                    if (keep) {
+                        const uint32_t* cs = g.cell_start + (size_t)o_bid * kBrickCells + (r << kBrickLog2);
+                        s[u] = cs[gx0 & (kBrickDim - 1)];
+                        e[u] = cs[(gx1 & (kBrickDim - 1)) + 1];
+                    }
                 }
-                jv[u] = cur_st + (f - cur_ex);
-                tv[u] = g.pts[jv[u]];
             }
+            // compact the non-empty segments into the group's LDS list, in segment order
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            uint32_t run_pts = 0, run_seg = 0;
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) consider(g, p, tv[u], (int)jv[u], best);
+            for (int u = 0; u < S; ++u) {
+                const uint32_t c2 = e[u] - s[u];
+                uint32_t in2 = c2;
+#pragma unroll
+                for (int o = 1; o < G; o <<= 1) {
+                    const uint32_t v = (uint32_t)__shfl_up((int)in2, o);
+                    if (sub >= o) in2 += v;
+                }
+                const uint32_t tot_u = (uint32_t)__shfl((int)in2, gbase + G - 1);
+                const unsigned m = (unsigned)(__ballot(c2 != 0) >> gbase) & gmask;
+                if (c2 != 0) {
+                    const uint32_t my = run_seg + (uint32_t)__popc(m & ((1u << sub) - 1u));
+                    seg_st[my] = s[u];
+                    seg_ex[my] = run_pts + in2 - c2;
+                }
+                run_pts += tot_u;
+                run_seg += (uint32_t)__popc(m);
+            }
+            if (run_pts == 0) continue;
+            if (sub == 0) seg_ex[run_seg] = run_pts;   // sentinel: end of the last segment
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            // phase 2: flattened scan, 4 independent 16-byte loads in flight per lane
+            uint32_t k = 0, cur_ex = 0, cur_st = seg_st[0], next_ex = seg_ex[1];
+            constexpr int kUnroll = 4;
+            for (uint32_t f0 = 0; f0 < run_pts; f0 += kUnroll * G) {
+                float4 tv[kUnroll];
+                uint32_t jv[kUnroll];
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    const uint32_t f = min(f0 + (uint32_t)(u * G + sub), run_pts - 1);   // clamp: duplicates are harmless
+                    while (f >= next_ex) {
+                        ++k;
+                        cur_ex = next_ex;
+                        cur_st = seg_st[k];
+                        next_ex = seg_ex[k + 1];
+                    }
+                    jv[u] = cur_st + (f - cur_ex);
+                    tv[u] = g.pts[jv[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) consider(g, p, tv[u], (int)jv[u], best);
+            }
         }
     }
+    return cover;
 }
 
 // `sub` = lane index inside the group (0..7); `first_level` < 0 tries the halo level first; `after_halo` is the regular
@@ -439,13 +544,20 @@ __device__ __forceinline__ void scan_level_wide(const Grid& g, const float3 p, i
 // kPrune: ball pruning of the wide level scan (search kernel of the select-based iterations, whose first launches scan
 // large boxes); the fused kernel, whose queries almost always end in the halo level, does without (it would cost it
 // registers beyond the 80 of 6 waves/SIMD).
+// *cov2_out (may be null): squared radius around p inside which EVERY reference point has been looked at; together with
+// Best::second this bounds how close any point other than the winner can be: d2(x) >= min(second, cov2) for all x != best
+// (the temporal-coherence shortcut of the next iterations relies on it; `slack` widens candidate-bounded boxes a little so
+// that the bound is not just the winner's own distance).
 template <int G, bool kPrune = false>
 __device__ __forceinline__ Best nearest_group(const Grid& g, float3 p, int sub, int first_level, int* level_out,
-                                              uint32_t* seg, int after_halo = -1) {
+                                              uint32_t* seg, int after_halo = -1, float* cov2_out = nullptr,
+                                              float slack = 0.f) {
     Best best;
     best.d2 = INFINITY;
     best.idx = 0xffffffffu;
     best.pos = -1;
+    best.second = INFINITY;
+    float cov = 0.f;   // radius covered so far
     const int gbase = (int)(threadIdx.x & 63) & ~(G - 1);  // first lane of this group in the wave
     int l = min(first_level, g.n_levels - 1);
     if (g.use_halo && first_level < 0) {
@@ -469,8 +581,10 @@ __device__ __forceinline__ Best nearest_group(const Grid& g, float3 p, int sub, 
             best = group_min_lazy<G>(g, best, gbase);
             const float rh = g.rho_h;
             const float rh2 = rh * rh;
+            cov = rh;
             if (best.pos >= 0 && best.d2 <= rh2) {
                 *level_out = -1;
+                if (cov2_out) *cov2_out = rh2;
                 return best;
             }
             if (best.pos >= 0 && best.idx == 0xffffffffu) best.idx = __float_as_uint(g.pts[best.pos].w);
@@ -485,7 +599,7 @@ __device__ __forceinline__ Best nearest_group(const Grid& g, float3 p, int sub, 
     }
     l = max(max(l, after_halo), 0);   // no halo level (or the query lies outside its grid): the hinted level
     for (; l < g.n_levels; ++l) {
-        scan_level_wide<G, kPrune>(g, p, sub, gbase, l, seg, best);
+        cov = fmaxf(cov, scan_level_rows<G, kPrune>(g, p, sub, gbase, l, seg, best, slack));
         best = group_min<G>(best);
         const float rw = g.rho[l];
         if (best.pos >= 0 && best.d2 <= rw * rw) break;   // every point within rho was inside the box: exact
@@ -500,6 +614,7 @@ __device__ __forceinline__ Best nearest_group(const Grid& g, float3 p, int sub, 
         }
     }
     *level_out = min(l, g.n_levels - 1);
+    if (cov2_out) *cov2_out = cov * cov;
     return best;
 }
 

@@ -27,6 +27,10 @@ struct IterState {
     float limit_last;         // trimmed limit of the last completed iteration (+inf: none)
     float limit_prev;         // ... and of the one before
     unsigned int band_count;  // records appended to the band buffer in this iteration
+    // coherent fused iteration: kQueues counters (one per 64 bytes: same-address returning atomics serialise at ~11 ns
+    // each, 800 workgroups on ONE word cost ~9 us) of the reading points whose shortcut failed, queued for k_coh_search;
+    // the update kernel clears them
+    unsigned int* qcount;
     unsigned int band_cap;
     int debug_narrow_band;    // test hooks: bit 0 forces band mispredictions, bit 1 disables the direct band ranking
     // R8x (X-ICP localizability, OptimizedEqualityConstraints)
@@ -68,6 +72,8 @@ struct HostMirror {
     } ring[16];
 };
 constexpr int kSeqRing = 16;
+constexpr int kQueues = 64;        // sub-queues of the coherent iteration's search queue (workgroup lb appends to lb % kQueues)
+constexpr int kQueueStride = 16;   // counters are 16 words (64 bytes) apart
 
 // XCD-aware workgroup order: the dispatcher deals workgroups round-robin over the 8 XCDs (blockIdx % 8
 // shares an XCD).  With a Morton-ordered reading, giving each XCD ONE contiguous eighth of the reading means

@@ -62,8 +62,9 @@ for occ, ratio, rho in itertools.product(occs, ratios, rhos):
         T0 = T
     same = bool(np.array_equal(T, T0))
     km = pr.prof_ms[0] / max(pr.prof_launches[0], 1) * 1e3
-    kf = pr.prof_ms[1] / max(pr.prof_launches[1], 1) * 1e3
+    kf = (pr.prof_ms[1] + pr.prof_ms[2]) / max(pr.prof_launches[1], 1) * 1e3
+    kf1 = pr.prof_ms[1] / max(pr.prof_launches[1], 1) * 1e3
     print(f"occ {occ:5.1f} ratio {ratio:4.2f} rho {rho:4.2f}: cell {info.cell_size:.4f} table {info.table_bytes / 1e6:8.1f} MB "
           f"build {res.target_build_ms:7.2f} ms | loop min {min(ms):.3f} med {sorted(ms)[len(ms) // 2]:.3f} ms | "
-          f"k_match {pr.prof_launches[0]:2d} x {km:6.1f} us, k_iter_fused {pr.prof_launches[1]:2d} x {kf:6.1f} us | "
+          f"k_match {pr.prof_launches[0]:2d} x {km:6.1f} us, k_iter_fused {pr.prof_launches[1]:2d} x {kf:6.1f} us (check {kf1:5.1f}) | "
           f"stalls {res.n_band_stalls} same pose {same}", flush=True)
