@@ -42,8 +42,11 @@ struct EnvSwitches {
     int lookahead = 2;          // O3D_KAHEAD
     float settle_tol = 0.25f;   // O3D_SETTLE
     float halo_ratio = 1.5f;    // O3D_HALO_RATIO: halo-bin edge in units of the brick-table bin edge (tuning sweeps)
-    float halo_rho = 0.25f;     // O3D_HALO_RHO: exactness radius of the halo level in units of the halo-bin edge
+    float halo_rho = 0.4f;      // O3D_HALO_RHO: exactness radius of the halo level in units of the halo-bin edge (round 2 sweep,
+                                // profiles/r02_table_sweep.txt: 0.4 beats 0.25 by 2-6 % on C2 / C3 / C4 -- fewer queries fall through
+                                // to the level scans, whose latency chain bounds the search kernels)
     float bin_occupancy = 8.f;  // O3D_BIN_OCC: points per occupied bin the automatic bin edge aims at
+    float level_ratio = 2.0f;   // O3D_LEVEL_RATIO: ratio of consecutive search radii (c/2, ... up to max_dist)
     void read() {
         trace = getenv("O3D_TRACE") != nullptr;
         event_timing = getenv("O3D_EVENT_TIMING") != nullptr;
@@ -56,6 +59,7 @@ struct EnvSwitches {
         if (const char* v = getenv("O3D_HALO_RATIO")) halo_ratio = std::min(4.0f, std::max(0.5f, (float)atof(v)));
         if (const char* v = getenv("O3D_HALO_RHO")) halo_rho = std::min(1.0f, std::max(0.05f, (float)atof(v)));
         if (const char* v = getenv("O3D_BIN_OCC")) bin_occupancy = std::min(64.0f, std::max(1.0f, (float)atof(v)));
+        if (const char* v = getenv("O3D_LEVEL_RATIO")) level_ratio = std::min(4.0f, std::max(1.2f, (float)atof(v)));
     }
 };
 
@@ -458,8 +462,8 @@ static void set_levels(reg_handle* h, float c, float max_abs) {
         g.rho[n] = rho;
         g.rho_box[n] = rho + 1e-3f * rho + abs_margin;
         ++n;
-        rho *= 2.0f;
-        if (std::isinf(md) && n >= 6) break;  // unbounded search: after 6 doublings fall through to a full scan
+        rho *= h->env.level_ratio;
+        if (std::isinf(md) && rho > 32.f * c) break;  // unbounded search: beyond 32 bin edges fall through to a full scan
     }
     g.rho[n] = md;
     g.rho_box[n] = std::isinf(md) ? INFINITY : md + 1e-3f * md + abs_margin;
@@ -633,25 +637,36 @@ static reg_status set_target_impl(reg_handle* h, const float* xyz, int64_t xyz_s
         if (s != REG_OK) return s;
     } else {
         const float ext = std::max(bmax[0] - bmin[0], std::max(bmax[1] - bmin[1], bmax[2] - bmin[2]));
-        // start from the edge that would give 8 points per bin if the cloud were a single ext x ext sheet
+        // start from the edge that would give `occ` points per bin if the cloud were a single ext x ext sheet, then correct
+        // with the measured occupancy (points per occupied bin grow with the square of the edge on surface-like clouds)
         const float occ = h->env.bin_occupancy;
-        cs = std::max(ext * std::sqrt(occ / (float)m), 1e-4f * std::max(ext, 1e-3f));
-        const float cs_min = std::max(ext / (float)(1u << 20), 1e-6f);
-        cs = std::max(cs, cs_min);
-        for (int pass = 0; pass < 3; ++pass) {
-            reg_status s = build_grid(h, cs, bmin, bmax, &occupied);
+        const float cs_abs = std::max(ext / (float)(1u << 20), 1e-6f);
+        cs = std::max(std::max(ext * std::sqrt(occ / (float)m), 1e-4f * std::max(ext, 1e-3f)), cs_abs);
+        auto build = [&](float& edge) {
+            reg_status s = build_grid(h, edge, bmin, bmax, &occupied);
             for (int grow = 0; s == REG_UNSUPPORTED && grow < 8; ++grow) {   // extent / edge^3 beyond the dense directory
-                cs *= 1.3f;
-                s = build_grid(h, cs, bmin, bmax, &occupied);
+                edge *= 1.3f;
+                s = build_grid(h, edge, bmin, bmax, &occupied);
             }
+            return s;
+        };
+        for (int pass = 0; pass < 3; ++pass) {
+            const reg_status s = build(cs);
             if (s != REG_OK) return s;
             const float per = (float)m / (float)std::max(1u, occupied);
-            if (per <= 1.5f * occ && per >= 0.625f * occ) break;
-            if (pass == 2) break;
-            float next = cs * std::sqrt(occ / per);
-            next = std::max(next, cs_min);
+            if ((per <= 1.15f * occ && per >= 0.85f * occ) || pass == 2) break;
+            const float next = std::max(cs * std::sqrt(occ / per), cs_abs);
             if (std::fabs(next - cs) < 0.05f * cs) break;
             cs = next;
+        }
+        // A bin box of the largest radius should not span more than ~15 bins per axis: the early iterations of a registration
+        // search with radii up to max_dist, and their cost grows with the number of rows in the box (measured at 20 M points:
+        // 0.050 m bins 3.48 ms per registration, 0.069 m bins 3.27 ms).
+        const float cs_reach = (std::isfinite(h->prm.max_dist) && !h->structure_only) ? h->prm.max_dist / 7.25f : 0.f;
+        if (cs < cs_reach) {
+            cs = cs_reach;
+            const reg_status s = build(cs);
+            if (s != REG_OK) return s;
         }
     }
     // sorted arrays

@@ -10,6 +10,8 @@ class glob:  # newest first: gpurun merges new runs next to older ones
 
 
 out = sys.argv[1]
+TAG = sys.argv[2] if len(sys.argv) > 2 else "r02"          # round tag of the files written under profiles/
+WL = sys.argv[3] if len(sys.argv) > 3 else "c3"            # workload the bench command ran (bench.py default: c3)
 dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
 os.makedirs(dst, exist_ok=True)
 
@@ -25,7 +27,7 @@ def counters(d):
 
 stats = glob.glob(os.path.join(out, "trace", "*", "*kernel_stats.csv"))
 if stats:
-    shutil.copy(stats[0], os.path.join(dst, "r01_bench_c2_kernel_stats.csv"))
+    shutil.copy(stats[0], os.path.join(dst, f"{TAG}_bench_{WL}_kernel_stats.csv"))
 trace = glob.glob(os.path.join(out, "trace", "*", "*kernel_trace.csv"))
 dur = collections.defaultdict(list)
 if trace:
@@ -39,10 +41,10 @@ for k, known in (("k_stream", float(1 << 30)), ("k_gather16", float((1 << 30) //
     if v:
         cal[k] = {"known_useful_bytes": known, "FETCH_SIZE_KiB_mean": sum(v) / len(v),
                   "reported_over_known": (sum(v) / len(v)) * 1024.0 / known}
-summary = {"command": "python bench.py --steps 10 --warmup 2 --no-cpu-baseline", "calibration": cal, "kernels": {}}
+summary = {"command": "python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras", "workload": WL, "calibration": cal, "kernels": {}}
 stream_ratio = cal.get("k_stream", {}).get("reported_over_known", 0.5)
 for k in sorted(set(fetch) | set(write)):
-    if not any(x in k for x in ("k_match", "k_iter_fused", "k_linearize", "k_reduce_update", "k_select", "k_hist")):
+    if not any(x in k for x in ("k_match", "k_iter_fused", "k_coh_", "k_linearize", "k_reduce_update", "k_select", "k_hist")):
         continue
     f = fetch.get(k, {}).get("FETCH_SIZE", [])
     w = write.get(k, {}).get("WRITE_SIZE", [])
@@ -55,38 +57,46 @@ for k in sorted(set(fetch) | set(write)):
         # gfx950: FETCH_SIZE counts 128-byte requests as 64 B for wide (16 B/lane) reads -> divide by the measured ratio
         "hbm_bytes_per_launch_corrected": ((sum(f) / len(f)) * 1024.0 / stream_ratio if f else 0.0) + ((sum(w) / len(w)) * 1024.0 if w else 0.0),
     }
-json.dump(summary, open(os.path.join(dst, "r01_pmc_traffic.json"), "w"), indent=1)
-with open(os.path.join(dst, "r01_bench_c2_trace_summary.txt"), "w") as fh:
+ks = summary["kernels"]
+chk = next((v for k, v in ks.items() if k.startswith("k_coh_check")), None)
+sea = next((v for k, v in ks.items() if k.startswith("k_coh_search")), None)
+if chk and sea and chk["launches"]:
+    ks["fused_pair"] = {"launches": chk["launches"], "avg_us": (chk["avg_us"] or 0) + (sea["avg_us"] or 0) * sea["launches"] / chk["launches"],
+                        "hbm_bytes_per_launch_corrected": chk["hbm_bytes_per_launch_corrected"] +
+                        sea["hbm_bytes_per_launch_corrected"] * sea["launches"] / chk["launches"],
+                        "note": "k_coh_check + k_coh_search: the fused iteration's search + linearisation (two launches)"}
+json.dump(summary, open(os.path.join(dst, f"{TAG}_pmc_traffic.json"), "w"), indent=1)
+with open(os.path.join(dst, f"{TAG}_bench_{WL}_trace_summary.txt"), "w") as fh:
     for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
         v2 = sorted(v)
         fh.write(f"{k[:60]:62s} n={len(v):5d} tot={sum(v)/1000:9.3f}ms avg={sum(v)/len(v):9.2f}us med={v2[len(v)//2]:9.2f} min={v2[0]:8.2f} max={v2[-1]:9.2f}\n")
 for line in open(os.path.join(out, "bench_trace.log")):
     if line.startswith('{"metric"'):
-        open(os.path.join(dst, "r01_bench_c2_line.json"), "w").write(line)
+        open(os.path.join(dst, f"{TAG}_bench_{WL}_line.json"), "w").write(line)
 nst = glob.glob(os.path.join(out, "normals", "*", "*kernel_stats.csv"))
 if nst:
     rows = list(csv.DictReader(open(nst[0])))
-    with open(os.path.join(dst, "r01_normals_1M_k10_kernel_stats.csv"), "w", newline="") as fh:
+    with open(os.path.join(dst, f"{TAG}_normals_1M_k10_kernel_stats.csv"), "w", newline="") as fh:
         w = csv.DictWriter(fh, fieldnames=rows[0].keys())
         w.writeheader()
         for r in rows:
             r["Name"] = r["Name"][:100]
             w.writerow(r)
-    with open(os.path.join(dst, "r01_normals_1M_k10_line.txt"), "w") as fh:
+    with open(os.path.join(dst, f"{TAG}_normals_1M_k10_line.txt"), "w") as fh:
         fh.writelines(l for l in open(os.path.join(out, "normals.log")) if l.startswith(("GPU", "CPU")))
 tp = os.path.join(out, "target_prep.log")
 if os.path.exists(tp):
-    with open(os.path.join(dst, "r01_target_prep_5M_line.txt"), "w") as fh:
+    with open(os.path.join(dst, f"{TAG}_target_prep_5M_line.txt"), "w") as fh:
         fh.writelines(l for l in open(tp) if l.startswith(("GPU", "host")))
 bp = os.path.join(out, "bench_plain.json")
 if os.path.exists(bp):
     for line in open(bp):
         if line.startswith('{"metric"'):
-            open(os.path.join(dst, "r01_bench_c2_line_unprofiled.json"), "w").write(line)
+            open(os.path.join(dst, f"{TAG}_bench_{WL}_line_unprofiled.json"), "w").write(line)
 tl = os.path.join(out, "timeline.txt")
 if os.path.exists(tl):
-    shutil.copy(tl, os.path.join(dst, "r01_registration_timeline.txt"))
+    shutil.copy(tl, os.path.join(dst, f"{TAG}_registration_timeline.txt"))
 sc = os.path.join(out, "scaling.txt")
 if os.path.exists(sc):
-    shutil.copy(sc, os.path.join(dst, "r01_search_kernels_vs_reading_size.txt"))
+    shutil.copy(sc, os.path.join(dst, f"{TAG}_search_kernels_vs_reading_size.txt"))
 print(json.dumps(summary, indent=1))
