@@ -1215,7 +1215,7 @@ reg_status reg_set_source(reg_handle* h, const float* xyz, int64_t xyz_stride, c
     HIPCHK(h, h->i_acc.reserve((size_t)kAccRows * kSums * 8));
     HIPCHK(h, h->i_sums.reserve(kSums * 8));
     HIPCHK(h, h->i_hint.reserve((size_t)n));
-    HIPCHK(h, h->i_cache.reserve((size_t)n * 48));   // per reading point: anchor + bound | matched point | its normal
+    HIPCHK(h, h->i_cache.reserve((size_t)n * 64));   // per reading point: anchor + bound | matched point | its normal | runner-up
     HIPCHK(h, h->i_queue.reserve(((size_t)((n + 255) / 256 + 63) / 64) * 256 * 64 * 4));   // kQueues sub-queues (coherent_queue_cap)
     if (!h->i_qcount.p) {
         HIPCHK(h, h->i_qcount.reserve(64 * 16 * 4));

@@ -375,7 +375,7 @@ __device__ __forceinline__ double coh_component(const float* E, int rows, int co
 __global__ void __launch_bounds__(256)
 k_coh_check(const float4* __restrict__ src, const float4* __restrict__ src_nrm, int64_t n, IterState* __restrict__ it,
             Grid g, const float4* __restrict__ tgt_nrm, FilterCfg f, int* __restrict__ pos_io, float* __restrict__ d2_out,
-            float* __restrict__ w_out, const float4* __restrict__ cache /* 3 x n: anchor | matched point | its normal */,
+            float* __restrict__ w_out, const float4* __restrict__ cache /* 4 x n: anchor | matched point | normal | runner-up */,
             uint32_t* __restrict__ queue, int queue_cap, float* __restrict__ band, int band_cap, double* __restrict__ partials,
             int n_blocks) {
     __shared__ __attribute__((aligned(16))) float E[256 * kCohRow];
@@ -394,6 +394,7 @@ k_coh_check(const float4* __restrict__ src, const float4* __restrict__ src_nrm, 
     const float4 c = cache[qc];
     const float4 tq = cache[(size_t)n + qc];
     const float4 nn = cache[2 * (size_t)n + qc];
+    const float4 ru = cache[3 * (size_t)n + qc];   // the runner-up of the last search (w = 1: valid, the bound excludes it)
     const int pprev = pos_io[qc];
     const int st_done = it->done, st_stall = it->stall;
     const Xf T = load_xf(it);
@@ -402,7 +403,7 @@ k_coh_check(const float4* __restrict__ src, const float4* __restrict__ src_nrm, 
 #pragma unroll
     for (int k = 0; k < 12; ++k) asm volatile("" ::"s"(T.m[k]));
     asm volatile("" ::"s"(band_lo), "s"(band_hi));
-    asm volatile("" ::"v"(s.x), "v"(c.w), "v"(pprev), "v"(tq.x), "v"(nn.x));
+    asm volatile("" ::"v"(s.x), "v"(c.w), "v"(pprev), "v"(tq.x), "v"(nn.x), "v"(ru.x));
     if ((st_done | st_stall) != 0) return;
     const float3 p = xf_point(T, s.x, s.y, s.z);
     // ---- does the previous neighbour provably remain the nearest one?
@@ -420,6 +421,19 @@ k_coh_check(const float4* __restrict__ src, const float4* __restrict__ src_nrm, 
         const float lhs = (__builtin_amdgcn_sqrtf(d2) + delta) * 1.00001f + 1e-30f;
         const float rhs = __builtin_amdgcn_sqrtf(c.w) * 0.99999f;
         pass = d2 <= g.max_d2 && lhs < rhs;
+        if (ru.w == 1.f) {
+            // Two-candidate form: the bound c.w covers every point EXCEPT the winner and the runner-up of the last search, so
+            // the runner-up is tested by itself -- with the comparison the full search would make (fp32 d2, strict: an exact
+            // tie is decided by the original indices, which only the full search knows).  Reading points that sit between
+            // two nearly equidistant reference points (8 % of C3, 25 % of C4 with the one-candidate bound) keep their match.
+            const float fx = p.x - ru.x, fy = p.y - ru.y, fz = p.z - ru.z;
+            float a2 = fx * fx;
+            float b2 = fy * fy;
+            float r2 = a2 + b2;
+            a2 = fz * fz;
+            r2 = r2 + a2;
+            pass = pass && d2 < r2;
+        }
         md2 = d2;
     }
     const bool need = q < n && !pass;
@@ -513,17 +527,24 @@ k_coh_search(const float4* __restrict__ src, const float4* __restrict__ src_nrm,
             const float3 p2 = xf_point(T, s2.x, s2.y, s2.z);
             int lvl;
             float cov2;
-            const Best bb = nearest_group<G>(g, p2, sub, -1, &lvl, seg_lds + grp * kSegWords<G>, hv >= 2 ? hv - 2 : -1, &cov2,
-                                             slack);
+            const Best bb = nearest_group<G, false, true>(g, p2, sub, -1, &lvl, seg_lds + grp * kSegWords<G>,
+                                                          hv >= 2 ? hv - 2 : -1, &cov2, slack);
             if (sub == 0) {
                 if (hint) hint[qq] = (uint8_t)(lvl + 1);
                 const int pc = bb.pos >= 0 ? bb.pos : 0;
                 const float4 tq = g.pts[pc];
                 float4 nn = tgt_nrm[pc];
                 nn.w = 1.f;
-                cache[qq] = make_float4(p2.x, p2.y, p2.z, bb.pos >= 0 ? fminf(bb.second, cov2) : -1.f);
+                float4 ru = make_float4(INFINITY, INFINITY, INFINITY, 1.f);   // no runner-up seen: infinitely far
+                if (bb.pos2 >= 0) {
+                    const float4 t2 = g.pts[bb.pos2];
+                    ru = make_float4(t2.x, t2.y, t2.z, 1.f);
+                }
+                // bound: every point other than the winner and the runner-up is at least sqrt(min(third, cov2)) away
+                cache[qq] = make_float4(p2.x, p2.y, p2.z, bb.pos >= 0 ? fminf(bb.third, cov2) : -1.f);
                 cache[(size_t)n + qq] = tq;
                 cache[2 * (size_t)n + qq] = nn;
+                cache[3 * (size_t)n + qq] = ru;
                 coh_epilogue(T, f, band_lo, band_hi, p2, qq, bb.pos, bb.d2, tq, nn, src_nrm, it, band, band_cap, pos_io, d2_out, w_out,
                              row);
             }

@@ -49,7 +49,8 @@ __global__ void __launch_bounds__(256, O3D_MATCH_WAVES)
 k_match_g8(const float4* __restrict__ src, int64_t n, const IterState* __restrict__ it, Grid g, int* __restrict__ pos,
            float* __restrict__ d2, uint32_t* __restrict__ hist0 /* 2048 or null */,
            uint32_t* __restrict__ hist2_to_zero, uint8_t* __restrict__ hint, int shift0, int debug, int n_blocks,
-           float4* __restrict__ cache /* anchor + bound for the temporal-coherence shortcut (k_iter_coherent), or null */) {
+           float4* __restrict__ cache /* 4 x n, or null: anchor + bound (row 0; row 3 = "no runner-up on record") for the
+                                         temporal-coherence shortcut of the fused iterations (k_coh_check) */) {
     __shared__ uint32_t sh[2048];
     __shared__ __attribute__((aligned(16))) uint32_t seg_lds[(256 / G) * kSegWords<G>];
     const int lb = xcd_block(n_blocks);
@@ -89,13 +90,19 @@ k_match_g8(const float4* __restrict__ src, int64_t n, const IterState* __restric
         const int hv = hint ? (int)hraw : 0;
         int lvl;
         float cov2;
+        // (one-candidate bound here: tracking the runner-up's identity in this kernel -- whose first launches scan thousands
+        // of candidates per point -- cost it 20 %, more than the fused iterations gain from the tighter bound; the fused
+        // iterations' own searches, k_coh_search, do track it)
         const Best b = nearest_group<G, true>(g, p, sub, -1, &lvl, seg_lds + (threadIdx.x / G) * kSegWords<G>,
                                         hv >= 2 ? hv - 2 : -1, &cov2);
         if (sub == 0) {
             pos[q] = b.pos;
             d2[q] = b.pos >= 0 ? b.d2 : INFINITY;
             if (hint) hint[q] = (uint8_t)(lvl + 1);
-            if (cache) cache[q] = make_float4(p.x, p.y, p.z, b.pos >= 0 ? fminf(b.second, cov2) : -1.f);
+            if (cache) {
+                cache[q] = make_float4(p.x, p.y, p.z, b.pos >= 0 ? fminf(b.second, cov2) : -1.f);
+                cache[3 * (size_t)n + q] = make_float4(0.f, 0.f, 0.f, 0.f);   // no runner-up on record: one-candidate bound
+            }
             if (hist0 && b.pos >= 0) atomicAdd(&sh[__float_as_uint(b.d2) >> shift0], 1u);
         }
     }
@@ -388,7 +395,7 @@ k_linearize_p2pl(const float4* __restrict__ src, const float4* __restrict__ src_
                  const float4* __restrict__ tgt_nrm, FilterCfg f, SelectState* __restrict__ st,
                  const uint32_t* __restrict__ hist2, uint32_t* __restrict__ hist1_to_zero, int shift0,
                  float* __restrict__ w_out, double* __restrict__ partials,
-                 float4* __restrict__ cache /* 3 x n (k_coh_check) or null: rows 1, 2 = matched point, its normal */) {
+                 float4* __restrict__ cache /* 4 x n (k_coh_check) or null: rows 1, 2 = matched point, its normal */) {
     // One batch for everything that does not depend on the match: match position, distance, reading point and normal
     // of this thread's point, the pose, the select state and this thread's 8 bins of the last radix level; then ONE
     // more batch for the matched point and its normal.  (It was a chain of six dependent round trips: done -> state ->

@@ -124,6 +124,9 @@ struct Best {
     uint32_t idx;  // original target index (tie-break: lowest wins)
     int pos;       // position in the sorted arrays
     float second;  // smallest d2 among the scanned points at a DIFFERENT position (group search only; +inf: none)
+    // kTop2 searches additionally keep WHICH point the runner-up is and the distance of the best point that is neither:
+    int pos2;      // position of the runner-up (-1: none)
+    float third;   // smallest d2 among the scanned points that are neither the winner nor the runner-up (+inf: none)
 };
 
 // Scan every target point in bins [lo, hi] (inclusive, already clamped to the grid).
@@ -172,6 +175,8 @@ __device__ __forceinline__ Best nearest(const Grid& g, float3 p) {
     best.idx = 0xffffffffu;
     best.pos = -1;
     best.second = INFINITY;
+    best.pos2 = -1;
+    best.third = INFINITY;
     for (int l = 0; l < g.n_levels; ++l) {
         const float rb = g.rho_box[l];
         // clamp in float before converting: handles +-inf radii and far-away queries
@@ -199,6 +204,7 @@ __device__ __forceinline__ Best nearest(const Grid& g, float3 p) {
 // -------------------------------------------------------------------------------------------------
 constexpr int kGroup = 8;   // default group width (lanes per reading point); kernels are templated on it
 
+template <bool kTop2 = false>
 __device__ __forceinline__ void consider(const Grid& g, float3 p, const float4 t, int j, Best& best) {
     const float dx = p.x - t.x, dy = p.y - t.y, dz = p.z - t.z;
     float a = dx * dx;
@@ -207,12 +213,24 @@ __device__ __forceinline__ void consider(const Grid& g, float3 p, const float4 t
     a = dz * dz;
     d2 = d2 + a;
     const uint32_t idx = __float_as_uint(t.w);
-    if (d2 <= g.max_d2 && j != best.pos) {   // (the clamped tail of a flattened scan re-reads its last point)
+    if (d2 <= g.max_d2 && j != best.pos && (!kTop2 || j != best.pos2)) {   // (the clamped tail of a flattened scan re-reads its last point)
         if (d2 < best.d2 || (d2 == best.d2 && idx < best.idx)) {
+            if (kTop2) {
+                best.third = best.second;
+                best.pos2 = best.pos;
+            }
             best.second = best.d2;           // the previous best becomes the runner-up
             best.d2 = d2;
             best.idx = idx;
             best.pos = j;
+        } else if (kTop2) {
+            if (d2 < best.second) {
+                best.third = best.second;
+                best.second = d2;
+                best.pos2 = j;
+            } else {
+                best.third = fminf(best.third, d2);
+            }
         } else {
             best.second = fminf(best.second, d2);
         }
@@ -239,7 +257,31 @@ __device__ __forceinline__ float group_second(const Best& mine, int winner_pos) 
     return c;
 }
 
+// kTop2: runner-up (distance AND position) and the best of the rest, from the lanes' own {winner, runner-up, third}.
+// `mine` = this lane's state before the merge, r.pos = the group's winner.
 template <int G>
+__device__ __forceinline__ void group_top2(const Best& mine, Best& r, int gbase) {
+    // every lane offers its best point other than the group's winner
+    const bool own = mine.pos == r.pos;
+    const float cd = own ? mine.second : mine.d2;
+    const int cp = own ? mine.pos2 : mine.pos;
+    float m2 = cd;
+#pragma unroll
+    for (int m = 1; m < G; m <<= 1) m2 = fminf(m2, __shfl_xor(m2, m));
+    const unsigned who = (unsigned)((__ballot(cd == m2 && cp >= 0) >> gbase) & ((1ull << G) - 1ull));
+    const int p2 = who ? __shfl(cp, gbase + __ffs((int)who) - 1) : -1;
+    // ... and its best point that is neither the winner nor the group's runner-up
+    float t = mine.third;
+    if (mine.pos >= 0 && mine.pos != r.pos && mine.pos != p2) t = fminf(t, mine.d2);
+    if (mine.pos2 >= 0 && mine.pos2 != r.pos && mine.pos2 != p2) t = fminf(t, mine.second);
+#pragma unroll
+    for (int m = 1; m < G; m <<= 1) t = fminf(t, __shfl_xor(t, m));
+    r.second = p2 >= 0 ? m2 : INFINITY;
+    r.pos2 = p2;
+    r.third = t;
+}
+
+template <int G, bool kTop2 = false>
 __device__ __forceinline__ Best group_min(Best b) {
     const Best mine = b;
 #pragma unroll
@@ -253,12 +295,16 @@ __device__ __forceinline__ Best group_min(Best b) {
             b.pos = opos;
         }
     }
-    b.second = group_second<G>(mine, b.pos);
+    if (kTop2)
+        group_top2<G>(mine, b, (int)(threadIdx.x & 63) & ~(G - 1));
+    else
+        b.second = group_second<G>(mine, b.pos);
     return b;
 }
 
 // Candidate from a halo record {x, y, z, bits(sorted position)}.  The original index (tie-break) is only
 // fetched when two candidates are exactly equidistant.
+template <bool kTop2 = false>
 __device__ __forceinline__ void consider_pos(const Grid& g, float3 p, const float4 t, Best& best) {
     const float dx = p.x - t.x, dy = p.y - t.y, dz = p.z - t.z;
     float a = dx * dx;
@@ -267,19 +313,36 @@ __device__ __forceinline__ void consider_pos(const Grid& g, float3 p, const floa
     a = dz * dz;
     d2 = d2 + a;
     const int pos = (int)__float_as_uint(t.w);
-    if (d2 <= g.max_d2 && pos != best.pos) {
+    if (d2 <= g.max_d2 && pos != best.pos && (!kTop2 || pos != best.pos2)) {
         if (d2 < best.d2) {
+            if (kTop2) {
+                best.third = best.second;
+                best.pos2 = best.pos;
+            }
             best.second = best.d2;
             best.d2 = d2;
             best.pos = pos;
             best.idx = 0xffffffffu;  // not fetched
         } else if (d2 == best.d2) {
-            best.second = d2;        // an exact tie: the runner-up is as close as the winner
+            // an exact tie: the runner-up is as close as the winner
             if (best.idx == 0xffffffffu) best.idx = __float_as_uint(g.pts[best.pos].w);
             const uint32_t idx = __float_as_uint(g.pts[pos].w);
+            if (kTop2) best.third = best.second;
+            best.second = d2;
             if (idx < best.idx) {
+                if (kTop2) best.pos2 = best.pos;
                 best.idx = idx;
                 best.pos = pos;
+            } else if (kTop2) {
+                best.pos2 = pos;
+            }
+        } else if (kTop2) {
+            if (d2 < best.second) {
+                best.third = best.second;
+                best.second = d2;
+                best.pos2 = pos;
+            } else {
+                best.third = fminf(best.third, d2);
             }
         } else {
             best.second = fminf(best.second, d2);
@@ -288,7 +351,7 @@ __device__ __forceinline__ void consider_pos(const Grid& g, float3 p, const floa
 }
 
 // Group minimum of (d2, original index) where idx may not have been fetched yet (0xffffffff).
-template <int G>
+template <int G, bool kTop2 = false>
 __device__ __forceinline__ Best group_min_lazy(const Grid& g, Best b, int gbase) {
     float m = b.d2;
 #pragma unroll
@@ -300,12 +363,17 @@ __device__ __forceinline__ Best group_min_lazy(const Grid& g, Best b, int gbase)
     r.idx = 0xffffffffu;
     r.pos = -1;
     r.second = INFINITY;
+    r.pos2 = -1;
+    r.third = INFINITY;
     if (mask == 0) return r;
     if ((mask & (mask - 1)) == 0) {  // exactly one lane holds the minimum
         r.d2 = m;
         r.pos = __shfl(b.pos, gbase + __ffs((int)mask) - 1);
         r.idx = (uint32_t)__shfl((int)b.idx, gbase + __ffs((int)mask) - 1);
-        r.second = group_second<G>(b, r.pos);
+        if (kTop2)
+            group_top2<G>(b, r, gbase);
+        else
+            r.second = group_second<G>(b, r.pos);
         return r;
     }
     // tie between lanes: lowest original index wins
@@ -318,7 +386,10 @@ __device__ __forceinline__ Best group_min_lazy(const Grid& g, Best b, int gbase)
     r.d2 = m;
     r.idx = mi;
     r.pos = __shfl(b.pos, gbase + __ffs((int)win) - 1);
-    r.second = group_second<G>(b, r.pos);
+    if (kTop2)
+        group_top2<G>(b, r, gbase);
+    else
+        r.second = group_second<G>(b, r.pos);
     return r;
 }
 
@@ -357,7 +428,7 @@ __device__ __forceinline__ int nth_set_bit64(uint32_t lo, uint32_t hi, int k) {
 // The scanned SET is unchanged (every point of every non-empty row inside the pruned box), hence the same exactness.
 // Returns the radius up to which every reference point is guaranteed to have been scanned (the level's rho, or -- when
 // the box was shrunk to a known candidate -- that candidate's distance plus `slack`).
-template <int G, bool kPrune>
+template <int G, bool kPrune, bool kTop2 = false>
 __device__ __forceinline__ float scan_level_rows(const Grid& g, const float3 p, int sub, int gbase, int l,
                                                  uint32_t* seg, Best& best, float slack) {
     constexpr int S = kSegPerLane, CAP = G * S;
@@ -525,7 +596,7 @@ __device__ __forceinline__ float scan_level_rows(const Grid& g, const float3 p, 
                     tv[u] = g.pts[jv[u]];
                 }
 #pragma unroll
-                for (int u = 0; u < kUnroll; ++u) consider(g, p, tv[u], (int)jv[u], best);
+                for (int u = 0; u < kUnroll; ++u) consider<kTop2>(g, p, tv[u], (int)jv[u], best);
             }
         }
     }
@@ -548,7 +619,7 @@ __device__ __forceinline__ float scan_level_rows(const Grid& g, const float3 p, 
 // Best::second this bounds how close any point other than the winner can be: d2(x) >= min(second, cov2) for all x != best
 // (the temporal-coherence shortcut of the next iterations relies on it; `slack` widens candidate-bounded boxes a little so
 // that the bound is not just the winner's own distance).
-template <int G, bool kPrune = false>
+template <int G, bool kPrune = false, bool kTop2 = false>
 __device__ __forceinline__ Best nearest_group(const Grid& g, float3 p, int sub, int first_level, int* level_out,
                                               uint32_t* seg, int after_halo = -1, float* cov2_out = nullptr,
                                               float slack = 0.f) {
@@ -557,6 +628,8 @@ __device__ __forceinline__ Best nearest_group(const Grid& g, float3 p, int sub, 
     best.idx = 0xffffffffu;
     best.pos = -1;
     best.second = INFINITY;
+    best.pos2 = -1;
+    best.third = INFINITY;
     float cov = 0.f;   // radius covered so far
     const int gbase = (int)(threadIdx.x & 63) & ~(G - 1);  // first lane of this group in the wave
     int l = min(first_level, g.n_levels - 1);
@@ -576,9 +649,9 @@ __device__ __forceinline__ Best nearest_group(const Grid& g, float3 p, int sub, 
 #pragma unroll
                 for (int u = 0; u < kU; ++u) tv[u] = g.halo_pts[min(j0 + (uint32_t)(u * G + sub), e - 1)];
 #pragma unroll
-                for (int u = 0; u < kU; ++u) consider_pos(g, p, tv[u], best);
+                for (int u = 0; u < kU; ++u) consider_pos<kTop2>(g, p, tv[u], best);
             }
-            best = group_min_lazy<G>(g, best, gbase);
+            best = group_min_lazy<G, kTop2>(g, best, gbase);
             const float rh = g.rho_h;
             const float rh2 = rh * rh;
             cov = rh;
@@ -599,8 +672,8 @@ __device__ __forceinline__ Best nearest_group(const Grid& g, float3 p, int sub, 
     }
     l = max(max(l, after_halo), 0);   // no halo level (or the query lies outside its grid): the hinted level
     for (; l < g.n_levels; ++l) {
-        cov = fmaxf(cov, scan_level_rows<G, kPrune>(g, p, sub, gbase, l, seg, best, slack));
-        best = group_min<G>(best);
+        cov = fmaxf(cov, scan_level_rows<G, kPrune, kTop2>(g, p, sub, gbase, l, seg, best, slack));
+        best = group_min<G, kTop2>(best);
         const float rw = g.rho[l];
         if (best.pos >= 0 && best.d2 <= rw * rw) break;   // every point within rho was inside the box: exact
         if (best.pos >= 0) {
