@@ -40,7 +40,8 @@ struct EnvSwitches {
     bool stamps = false;        // O3D_STAMPS: in-kernel cycle stamps of the update kernel
     bool coh_stats = false;     // O3D_COH_STATS: share of the reading points the coherent fused kernel had to search
     int lookahead = 2;          // O3D_KAHEAD
-    float settle_tol = 0.25f;   // O3D_SETTLE
+    float settle_tol = 0.05f;   // O3D_SETTLE: relative change of the trimmed limit below which the fused iterations start (round 2 sweep:
+                                // 0.05 beats 0.25 by 5 % on C3 -- an early fused iteration has a wide band and moves every point by millimetres)
     float halo_ratio = 1.5f;    // O3D_HALO_RATIO: halo-bin edge in units of the brick-table bin edge (tuning sweeps)
     float halo_rho = 0.4f;      // O3D_HALO_RHO: exactness radius of the halo level in units of the halo-bin edge (round 2 sweep,
                                 // profiles/r02_table_sweep.txt: 0.4 beats 0.25 by 2-6 % on C2 / C3 / C4 -- fewer queries fall through

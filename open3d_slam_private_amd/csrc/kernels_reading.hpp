@@ -155,3 +155,4 @@ __global__ void k_pack_cov(const float* __restrict__ cov, int64_t n, const uint3
     out[2 * i] = make_float4(q[0], q[1], q[2], q[3]);
     out[2 * i + 1] = make_float4(q[4], q[5], 0.f, 0.f);
 }
+
