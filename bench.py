@@ -431,6 +431,12 @@ def main():
                          "bytes_per_point": bytes_pp,
                          "limiter": "latency of dependent round trips, then Infinity-Cache/HBM fetches of the candidate "
                                     "records an exact search has to look at (DESIGN.md section 6, profiles/)"},
+            "roofline_fused": (None if multi or "fused_pair" not in kern else {
+                "bound": "hbm", "kernel": "k_coh_check + k_coh_search (settled iterations: search + linearisation)",
+                "achieved": n_local * 48 / (kern["fused_pair"]["avg_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": n_local * 48 / (kern["fused_pair"]["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "traffic": pmc_traffic(workload, "fused_pair")[0], "algorithmic_bytes_per_launch": n_local * 48,
+                "kernel_ms": kern["fused_pair"]["avg_ms"], "launches": kern["fused_pair"]["launches"]}),
             "kernels": kern,
             "roofline_iteration": {"bytes_per_point": ITER_BYTES_PER_POINT,
                                    "achieved_GBs_end_to_end": n_global * ITER_BYTES_PER_POINT * ITERS * args.steps / elapsed / 1e9},

@@ -62,8 +62,26 @@ int main() {
                     r.converged, (long long)r.n_inliers, std::atan2(T[1], T[0]) * 180.0 / 3.14159265, T[12], T[13], T[14]);
         const bool ok = std::fabs(std::atan2(T[1], T[0]) - a) < 2e-3 && std::fabs(T[12] - 0.05f) < 5e-3 &&
                         std::fabs(T[13] + 0.03f) < 5e-3 && std::fabs(T[14] - 0.02f) < 5e-3;
-        std::printf(ok ? "OK\n" : "MISMATCH\n");
-        return ok ? 0 : 1;
+        // the same scan as Open3D holds it (fp64), cast on the device: the same transform
+        std::vector<double> rd64(3 * (size_t)N), rdn64(3 * (size_t)N);
+        for (int i = 0; i < N; ++i)
+            for (int k = 0; k < 3; ++k) {
+                rd64[3 * i + k] = rd[4 * i + k];
+                rdn64[3 * i + k] = rdn[3 * i + k];
+            }
+        const auto T64 = icp.computeF64(rd64.data(), rdn64.data(), N, false, o3dreg::identity4());
+        bool same64 = true;
+        for (int k = 0; k < 16; ++k) same64 = same64 && T64[k] == T[k];
+        // the multi-GPU loop (C++ steering + RCCL collectives) with a group of ONE rank: the same transform again
+        icp.joinGroup(o3dreg::ICP::makeGroupId(), 0, 1);
+        const auto Tp = icp.computePartitioned(reading, o3dreg::identity4());
+        icp.leaveGroup();
+        float dmax = 0.f;
+        for (int k = 0; k < 16; ++k) dmax = std::fmax(dmax, std::fabs(Tp[k] - T[k]));
+        std::printf("fp64 reading: %s; partitioned loop (1 rank, RCCL): max |dT| = %.2e\n", same64 ? "identical" : "DIFFERENT", dmax);
+        const bool ok2 = same64 && dmax < 1e-5f;
+        std::printf(ok && ok2 ? "OK\n" : "MISMATCH\n");
+        return ok && ok2 ? 0 : 1;
     } catch (const std::exception& e) {
         std::fprintf(stderr, "error: %s\n", e.what());
         return 3;

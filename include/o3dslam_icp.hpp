@@ -89,6 +89,47 @@ public:
         return compute(readingIn, referenceIn, identity4(), true);
     }
 
+    // The scan as Mapper::addRangeMeasurement holds it before open3dToPointmatcher (Mapper.cpp:288-289): Open3D's fp64
+    // arrays (points_ / normals_ n x 3 doubles).  Cast on the device (open3d_conversions.cpp:57-118), then compute().
+    TransformationParameters computeF64(const double* points, const double* normals, int64_t n, bool on_device,
+                                        const TransformationParameters& T_refIn_readIn) {
+        ensure();
+        if (!matcherIsInitialized_) throw std::runtime_error("You must call initReference first");
+        if (n == 0) throw std::runtime_error("The reading point cloud is empty.");
+        check(reg_set_source_f64(h_, points, normals, nullptr, n, on_device ? 1 : 0));
+        TransformationParameters out = T_refIn_readIn;
+        check(reg_register(h_, T_refIn_readIn.data(), out.data(), &last_));
+        return out;
+    }
+
+    // ---- one process per GPU, reading partitioned over the group (BASELINE config C4) --------------------------------
+    // Rank 0 creates the 128-byte id (ICP::makeGroupId) and hands it to the other ranks; every rank joins with its rank.
+    static std::array<char, REG_DIST_ID_BYTES> makeGroupId() {
+        std::array<char, REG_DIST_ID_BYTES> id{};
+        if (reg_dist_get_unique_id(id.data()) != REG_OK) throw DeviceError("ncclGetUniqueId failed (is librccl loadable?)");
+        return id;
+    }
+    void joinGroup(const std::array<char, REG_DIST_ID_BYTES>& id, int rank, int n_ranks) {
+        ensure();
+        check(reg_dist_init(h_, id.data(), rank, n_ranks));
+    }
+    void leaveGroup() { if (h_) check(reg_dist_shutdown(h_)); }
+    // ICP::compute for THIS RANK'S SLICE of the reading; collective: every rank calls it with the same T and returns the
+    // same transform (lastResult() carries the global figures).  The reference is the one given to initReference on
+    // every rank (replicated).
+    TransformationParameters computePartitioned(const DataPointsView& readingSlice,
+                                                const TransformationParameters& T_refIn_readIn) {
+        ensure();
+        if (!matcherIsInitialized_) throw std::runtime_error("You must call initReference first");
+        if (readingSlice.getNbPoints() == 0) throw std::runtime_error("The reading point cloud is empty.");
+        check(reg_set_source(h_, readingSlice.features, readingSlice.feature_stride, readingSlice.normals,
+                             readingSlice.normal_stride, readingSlice.covariances, readingSlice.n,
+                             readingSlice.on_device ? 1 : 0));
+        TransformationParameters out = T_refIn_readIn;
+        check(reg_dist_register(h_, T_refIn_readIn.data(), out.data(), &last_));
+        return out;
+    }
+
 private:
     void reset() { if (h_) { reg_destroy(h_); h_ = nullptr; } matcherIsInitialized_ = false; }
     void ensure() {
