@@ -672,7 +672,7 @@ static reg_status set_target_impl(reg_handle* h, const float* xyz, int64_t xyz_s
     }
     // sorted arrays
     HIPCHK(h, h->t_pts.reserve((size_t)m * 16));
-    if (d_nrm) HIPCHK(h, h->t_nrm.reserve((size_t)m * 16));
+    if (d_nrm) HIPCHK(h, h->t_nrm.reserve((size_t)m * 32));   // {point, normal} pairs in sorted order
     if (d_cov) HIPCHK(h, h->t_cov.reserve((size_t)m * 32));
     k_gather_target<<<grid_for(m), 256, 0, h->stream>>>(h->t_centred.as<float4>(), h->t_vals2.as<uint32_t>(), m, d_nrm,
                                                          nrm_stride, d_cov, h->t_pts.as<float4>(),

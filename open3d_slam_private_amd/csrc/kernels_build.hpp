@@ -111,10 +111,14 @@ __global__ void k_gather_target(const float4* __restrict__ centred, const uint32
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t src = order[i];
-    pts_sorted[i] = centred[src];
+    const float4 pt = centred[src];
+    pts_sorted[i] = pt;
     if (nrm_sorted) {
+        // point and normal INTERLEAVED (32 bytes, one 128-byte line holds four pairs): whoever needs the matched point's
+        // normal needs the point too, and a random 16-byte gather costs a whole line -- two arrays meant two lines per match
         const float* q = nrm + (int64_t)src * nrm_stride;
-        nrm_sorted[i] = make_float4(q[0], q[1], q[2], 0.f);
+        nrm_sorted[2 * i] = pt;
+        nrm_sorted[2 * i + 1] = make_float4(q[0], q[1], q[2], 0.f);
     }
     if (cov_sorted) {
         const float* q = cov + (int64_t)src * 6;

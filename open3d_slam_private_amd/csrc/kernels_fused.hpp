@@ -137,8 +137,8 @@ k_iter_fused(const float4* __restrict__ src, const float4* __restrict__ src_nrm,
             dd = b.d2;
             w = 1.f;
             if (f.use_maxdist && !(dd <= f.outlier_max_d2)) w = 0.f;
-            const float4 nn = tgt_nrm[b.pos];
-            const float4 tq = g.pts[b.pos];   // requested with the normal (only kept points use it: one round trip less)
+            const float4 nn = tgt_nrm[2 * (size_t)b.pos + 1];
+            const float4 tq = tgt_nrm[2 * (size_t)b.pos];   // {point, normal} pair: requested together, one line
             // factor codes of the CP components this lane owns (same batch; 64 bytes shared by every wave)
 #pragma unroll
             for (int wi = 0; wi < CP / 4; ++wi) {
@@ -532,8 +532,8 @@ k_coh_search(const float4* __restrict__ src, const float4* __restrict__ src_nrm,
             if (sub == 0) {
                 if (hint) hint[qq] = (uint8_t)(lvl + 1);
                 const int pc = bb.pos >= 0 ? bb.pos : 0;
-                const float4 tq = g.pts[pc];
-                float4 nn = tgt_nrm[pc];
+                const float4 tq = tgt_nrm[2 * (size_t)pc];       // {point, normal} pair: one line
+                float4 nn = tgt_nrm[2 * (size_t)pc + 1];
                 nn.w = 1.f;
                 float4 ru = make_float4(INFINITY, INFINITY, INFINITY, 1.f);   // no runner-up seen: infinitely far
                 if (bb.pos2 >= 0) {

@@ -419,8 +419,8 @@ k_linearize_p2pl(const float4* __restrict__ src, const float4* __restrict__ src_
     if (st_done) return;
     const int ps = i < n ? ps_raw : -1;
     const int psc = ps >= 0 ? ps : 0;
-    const float4 nn_ld = tgt_nrm[psc];
-    const float4 q_ld = tgt[psc];
+    const float4 nn_ld = tgt_nrm[2 * (size_t)psc + 1];   // {point, normal} pair: one line
+    const float4 q_ld = tgt_nrm[2 * (size_t)psc];
     // trimmed-quantile limit: last radix level, re-derived by every workgroup (f.use_trim == 2),
     // or taken from the state as given by the caller (f.use_trim == 1: distributed path)
     float limit = INFINITY;

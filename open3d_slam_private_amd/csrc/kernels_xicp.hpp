@@ -93,7 +93,7 @@ k_xicp_detect(const float4* __restrict__ src, int64_t n, const IterState* __rest
         ps.x = ps.x - c[0];
         ps.y = ps.y - c[1];
         ps.z = ps.z - c[2];
-        const float4 nr = tgt_nrm[j];
+        const float4 nr = tgt_nrm[2 * (size_t)j + 1];   // {point, normal} pairs
         const float3 nn = xicp_to_data_frame_vec(Trd, nr.x, nr.y, nr.z);
         float cr[3];
         float u, q;

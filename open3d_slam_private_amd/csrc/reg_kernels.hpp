@@ -657,7 +657,9 @@ __device__ __forceinline__ Best nearest_group(const Grid& g, float3 p, int sub, 
             cov = rh;
             if (best.pos >= 0 && best.d2 <= rh2) {
                 *level_out = -1;
-                if (cov2_out) *cov2_out = rh2;
+                // (capped at max_dist: points beyond it are not candidates, hence not in `second` either -- found by the
+                // round-2 fuzz: halo radius 0.24 m with maxDist 0.2 m let a point 0.22 m away go unnoticed by the bound)
+                if (cov2_out) *cov2_out = fminf(rh2, g.max_d2);
                 return best;
             }
             if (best.pos >= 0 && best.idx == 0xffffffffu) best.idx = __float_as_uint(g.pts[best.pos].w);
@@ -687,7 +689,7 @@ __device__ __forceinline__ Best nearest_group(const Grid& g, float3 p, int sub, 
         }
     }
     *level_out = min(l, g.n_levels - 1);
-    if (cov2_out) *cov2_out = cov * cov;
+    if (cov2_out) *cov2_out = fminf(cov * cov, g.max_d2);
     return best;
 }
 

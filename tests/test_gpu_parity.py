@@ -1013,3 +1013,31 @@ def test_non_orthogonal_initial_guess_is_corrected_like_the_reference(shear, exp
     assert res.iterations == ores.iterations
     dt = float(np.abs(T - To).max())
     assert dt <= 1e-4, dt
+
+
+@pytest.mark.parametrize("max_dist,cell,use_trim", [(0.2, 0.4, 0), (0.05, 0.4, 0), (0.5, 0.0, 0), (0.2, 0.0, 1)])
+def test_coherence_shortcut_with_halo_radius_beyond_max_dist(max_dist, cell, use_trim):
+    """Round-2 fuzz finding: the bound of the temporal-coherence shortcut (every point other than the winner is at least
+    sqrt(min(runner-up d2, covered radius^2)) away from the anchor) must not use a covered radius beyond max_dist -- points
+    farther than max_dist are not candidates, so the search never put them into `runner-up`.  With a halo radius of 0.24 m
+    and maxDist 0.2 m a point 0.22 m away went unnoticed and a later iteration kept a neighbour that was no longer the
+    nearest.  Chains without TrimmedDist fuse from the second iteration on (large motion): the fused iterations
+    (k_coh_check + k_coh_search) must reproduce the select-based ones bit for bit, and so must the round-1 fused kernel."""
+    sc = synth.make_scene(9000, 20000 if cell else 700, seed=4711)
+    outs = []
+    for kw in (dict(disable_fused=1), dict(), dict(debug_flags=16)):
+        p = capi.shipped_params()
+        p.max_dist, p.cell_size, p.use_trimmed, p.max_iter = max_dist, cell, use_trim, 25
+        for k, v in kw.items():
+            setattr(p, k, v)
+        reg = capi.Registration(p)
+        reg.set_target(sc.tgt_xyz, sc.tgt_nrm)
+        reg.set_source(sc.src_xyz, sc.src_nrm)
+        T, res = reg.register(np.eye(4))
+        ids, d2, w = reg.correspondences()
+        outs.append((T, res.iterations, ids, d2, w))
+        reg.close()
+    Tg, itg, idsg, d2g, wg = outs[0]
+    for T, it, ids, d2, w in outs[1:]:
+        assert it == itg and np.array_equal(T, Tg)
+        assert np.array_equal(ids, idsg) and np.array_equal(d2.view(np.uint32), d2g.view(np.uint32)) and np.array_equal(w, wg)

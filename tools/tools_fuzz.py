@@ -75,17 +75,53 @@ for case in range(n_cases):
             To, ores = orc.icp_p2pl(sc.tgt_xyz, sc.tgt_nrm, sc.src_xyz, sc.src_nrm, T0, max_dist=p.max_dist,
                                     trim_ratio=p.trim_ratio if p.use_trimmed else None,
                                     max_normal_angle=p.max_normal_angle, max_iter=p.max_iter, min_diff_rot=p.min_diff_rot,
-                                    min_diff_trans=p.min_diff_trans, smooth_len=p.smooth_len, n_threads=16)
+                                    min_diff_trans=p.min_diff_trans, smooth_len=p.smooth_len, n_threads=16,
+                                    xicp=(250, 180, 80, 45))   # reg_shipped_params has the degeneracy awareness on
             o_fail = ores.status == 3
         except RuntimeError:
             o_fail = True
+        # round 2: the temporal-coherence kernels against the round-1 fused kernel (debug_flags 16), same binary: the whole
+        # registration must be bit-identical (pose, ids, d2, weights of the last iteration)
+        coh_same = True
+        if not g_fail:
+            ids_c, d2_c, w_c = reg.correspondences()
+            p16 = capi.shipped_params()
+            for fld in ("max_dist", "trim_ratio", "use_trimmed", "cell_size", "max_iter"):
+                setattr(p16, fld, getattr(p, fld))
+            p16.lanes_per_point = p.lanes_per_point
+            p16.debug_flags = 16
+            r16 = capi.Registration(p16)
+            r16.set_target(sc.tgt_xyz, sc.tgt_nrm)
+            r16.set_source(sc.src_xyz, sc.src_nrm)
+            T16, res16 = r16.register(T0)
+            ids16, d216, w16 = r16.correspondences()
+            r16.close()
+            coh_same = (np.array_equal(T, T16) and res.iterations == res16.iterations and np.array_equal(ids_c, ids16) and
+                        np.array_equal(d2_c.view(np.uint32), d216.view(np.uint32)) and np.array_equal(w_c, w16))
+            if not coh_same:
+                print(f"   coherent vs legacy: T equal {np.array_equal(T, T16)} (max |dT| {np.abs(T - T16).max():.2e}) iterations {res.iterations}/{res16.iterations} "
+                      f"ids differ {(ids_c != ids16).sum()} d2 differ {(d2_c.view(np.uint32) != d216.view(np.uint32)).sum()} w differ {(w_c != w16).sum()} "
+                      f"inliers {res.n_inliers}/{res16.n_inliers} matched {res.n_matched}/{res16.n_matched} stalls {res.n_band_stalls}/{res16.n_band_stalls}")
+                # which of the two is right?  the select-based path (every iteration through k_match_g8, whose matches the
+                # linearisation check above compares with the oracle) is the referee
+                p16.debug_flags = 0
+                p16.disable_fused = 1
+                rg = capi.Registration(p16)
+                rg.set_target(sc.tgt_xyz, sc.tgt_nrm)
+                rg.set_source(sc.src_xyz, sc.src_nrm)
+                Tg, resg = rg.register(T0)
+                idsg, d2g, wg = rg.correspondences()
+                rg.close()
+                print(f"   referee (select-based only): coherent T equal {np.array_equal(T, Tg)} ids differ {(ids_c != idsg).sum()}; "
+                      f"legacy T equal {np.array_equal(T16, Tg)} ids differ {(ids16 != idsg).sum()}")
+            ok = ok and coh_same
         if g_fail or o_fail:
             ok = ok and g_fail == o_fail
             detail = f"ids {same_ids} no correspondences: product {g_fail} oracle {o_fail}"
         else:
             dt, dr = synth.pose_error(T, To)
             ok = ok and dt <= 1e-4 and dr <= 1e-4 and res.iterations == ores.iterations
-            detail = f"ids {same_ids} d2 {same_d2} pose {dt:.1e}/{dr:.1e} it {res.iterations}/{ores.iterations}"
+            detail = f"ids {same_ids} d2 {same_d2} pose {dt:.1e}/{dr:.1e} it {res.iterations}/{ores.iterations} coherent==legacy {coh_same}"
     except capi.RegError as e:
         detail = f"unexpected RegError {e.status}: {e}"
         ok = False
