@@ -363,6 +363,7 @@ static inline unsigned long long mirror_seq(const reg_handle* h) {
 static reg_status wait_seq(reg_handle* h, unsigned long long seq) {
     for (unsigned spins = 0;; ++spins) {
         if (mirror_seq(h) >= seq) return REG_OK;
+        __builtin_ia32_pause();          // the sibling hyper-thread may be another handle's enqueueing thread
         if ((spins & 0x3fff) == 0x3fff) {
             hipError_t e = hipStreamQuery(h->stream);
             if (e == hipSuccess) return REG_OK;  // everything enqueued has run (later iterations were no-ops)
