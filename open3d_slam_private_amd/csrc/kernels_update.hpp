@@ -133,11 +133,13 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
     constexpr int kSpec = 6;
     const bool spec = fused == 1 && !gathered && band != nullptr;
     uint32_t spec_d2 = 0;
+    int spec_idx = 0;               // the record's point index (component 31): only read when the record is trimmed away
     float spec_pre[kSpec];
 #pragma unroll
     for (int u = 0; u < kSpec; ++u) spec_pre[u] = 0.f;
     if (spec) {
         spec_d2 = __float_as_uint(band[band_at(29, threadIdx.x)]);
+        if (w_out) spec_idx = __float_as_int(band[band_at(31, threadIdx.x)]);
         if (comp != 29 && comp != 31) {
 #pragma unroll
             for (int u = 0; u < kSpec; ++u) spec_pre[u] = band[band_at(comp, (uint32_t)part + 32u * u)];
@@ -411,20 +413,20 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
                 for (uint32_t i = threadIdx.x; i < n_band; i += 1024) {
                     if (!(__uint_as_float(bd2[i]) <= limit)) {
                         if (!gathered) {
-                            w_out[__float_as_int(rec(i, 31))] = 0.f;
+                            w_out[(spec && i < 1024u) ? spec_idx : __float_as_int(rec(i, 31))] = 0.f;
                         } else if (i >= rk_off[my_rank] && i < rk_off[my_rank + 1]) {
                             w_out[__float_as_int(rec(i, 31))] = 0.f;   // only this rank's own points
                         }
                     }
                 }
-            __syncthreads();
+            lds_barrier();   // LDS-only: the weight stores above drain behind the solve (the kernel's end orders them)
             if (threadIdx.x < kSums) {
                 double s2 = 0;
 #pragma unroll
                 for (int p = 0; p < 16; ++p) s2 += sh[p][threadIdx.x];
                 tot[threadIdx.x] += s2;
             }
-            __syncthreads();
+            lds_barrier();
             stC = __builtin_amdgcn_s_memtime();
         }
     } else if (!fused && trim && sel) {
