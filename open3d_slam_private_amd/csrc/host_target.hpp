@@ -472,8 +472,8 @@ static void set_levels(reg_handle* h, float c, float max_abs) {
     g.n_levels = n;
 }
 
-// Level-0 accelerator: dense halo bins of edge c_h = 1.5 c with rho_h = c_h / 4 (each point is listed in
-// 1-2 bins per axis: ~3.4 copies).  Skipped when the dense grid would be too large or on request.
+// Level-0 accelerator: dense halo bins of edge c_h = 1.5 c with rho_h = 0.4 c_h (O3D_HALO_RHO; each point is listed in
+// 1-2 bins per axis: ~4.5 copies).  Skipped when the dense grid would be too large or on request.
 static reg_status build_halo(reg_handle* h, float c, const float bmin[3], const float bmax[3], float max_abs) {
     Grid& g = h->grid;
     g.use_halo = 0;
