@@ -187,15 +187,16 @@ reg_status reg_dist_fused_buffers(reg_handle* h, int n_ranks, int rank, void** c
         return REG_BAD_ARGUMENT;
     if (h->n == 0) return REG_NOT_CONFIGURED;
     HIPCHK(h, hipSetDevice(h->prm.device));
-    HIPCHK(h, h->d_contrib.reserve((size_t)kContribFloats * 4));
-    HIPCHK(h, h->d_gathered.reserve((size_t)n_ranks * kContribFloats * 4));
-    HIPCHK(h, hipMemsetAsync(h->d_contrib.p, 0, (size_t)kContribFloats * 4, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->d_gathered.p, 0, (size_t)n_ranks * kContribFloats * 4, h->stream));
+    const size_t block_bytes = contrib_floats(contrib_cap_for(n_ranks)) * 4;
+    HIPCHK(h, h->d_contrib.reserve(block_bytes));
+    HIPCHK(h, h->d_gathered.reserve((size_t)n_ranks * block_bytes));
+    HIPCHK(h, hipMemsetAsync(h->d_contrib.p, 0, block_bytes, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_gathered.p, 0, (size_t)n_ranks * block_bytes, h->stream));
     h->dist_ranks = n_ranks;
     h->dist_rank = rank;
     *contrib = h->d_contrib.p;
     *gathered = h->d_gathered.p;
-    *contrib_bytes = (int64_t)kContribFloats * 4;
+    *contrib_bytes = (int64_t)block_bytes;
     return REG_OK;
 }
 
@@ -342,19 +343,19 @@ reg_status reg_dist_phase(reg_handle* h, int phase) {
                 k_iter_fused<8><<<8 * ((blocks + 7) / 8), 256, 0, h->stream>>>(
                     h->s_xyz.as<float4>(), h->has_snrm ? h->s_nrm.as<float4>() : nullptr, h->n, h->i_iter.as<IterState>(),
                     h->grid, h->t_nrm.as<float4>(), f, h->i_pos.as<int>(), h->i_d2.as<float>(), h->i_w.as<float>(), hint,
-                    contrib + kContribHdr, kContribCap, h->i_acc.as<double>(), blocks);
+                    contrib + kContribHdr, contrib_cap_for(h->dist_ranks), h->i_acc.as<double>(), blocks);
             } else {
                 const int blocks = grid_for(h->n);
                 k_coh_check<<<8 * ((blocks + 7) / 8), 256, 0, h->stream>>>(
                     h->s_xyz.as<float4>(), h->has_snrm ? h->s_nrm.as<float4>() : nullptr, h->n, h->i_iter.as<IterState>(),
                     h->grid, h->t_nrm.as<float4>(), f, h->i_pos.as<int>(), h->i_d2.as<float>(), h->i_w.as<float>(),
                     h->i_cache.as<float4>(), h->i_queue.as<uint32_t>(), coherent_queue_cap(h->n), contrib + kContribHdr,
-                    kContribCap, h->i_acc.as<double>(), blocks);
+                    contrib_cap_for(h->dist_ranks), h->i_acc.as<double>(), blocks);
                 k_coh_search<8><<<coherent_search_grid(h), 256, 0, h->stream>>>(
                     h->s_xyz.as<float4>(), h->has_snrm ? h->s_nrm.as<float4>() : nullptr, h->n, h->i_iter.as<IterState>(),
                     h->grid, h->t_nrm.as<float4>(), f, h->i_pos.as<int>(), h->i_d2.as<float>(), h->i_w.as<float>(), hint,
                     h->i_cache.as<float4>(), h->i_queue.as<uint32_t>(), coherent_queue_cap(h->n), contrib + kContribHdr,
-                    kContribCap, h->i_acc.as<double>(), coherent_slack(h), (CohStats*)nullptr);
+                    contrib_cap_for(h->dist_ranks), h->i_acc.as<double>(), coherent_slack(h), (CohStats*)nullptr);
             }
             k_pack_contrib<<<1, 64, 0, h->stream>>>(h->i_acc.as<double>(), it, contrib);
             h->have_match = true;

@@ -457,7 +457,7 @@ static reg_status dist_enqueue_generic(reg_handle* h, bool* xicp_first) {
 static reg_status dist_enqueue_fused(reg_handle* h) {
     reg_status s;
     if ((s = reg_dist_phase(h, 5)) != REG_OK) return s;
-    if ((s = dist_all_gather(h, h->d_contrib.p, h->d_gathered.p, (int64_t)kContribFloats * 4)) != REG_OK) return s;
+    if ((s = dist_all_gather(h, h->d_contrib.p, h->d_gathered.p, (int64_t)(contrib_floats(contrib_cap_for(h->dist_ranks)) * 4))) != REG_OK) return s;
     return reg_dist_phase(h, 6);
 }
 

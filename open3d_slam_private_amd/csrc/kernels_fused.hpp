@@ -15,10 +15,14 @@
 // the generic path by construction: same products, same fp64 accumulation, exact quantile.
 constexpr int kBandCap = 16384;
 // Multi-GPU fused iteration: every rank contributes one fixed-size block {32 double sums, band count, up to
-// kContribCap band records}; ONE all-gather per iteration hands every rank all blocks.
+// `cap` band records}; ONE all-gather per iteration hands every rank all blocks.  The capacity depends on the group
+// size: a settled band holds 500-4000 records of a 200 k-point reading IN TOTAL (C4, measured), so a rank of a small group
+// needs room for more of them; the all-gather moves ~1 MB per iteration whatever the group size (<= 8 ranks).
 constexpr int kContribHdr = 128;                       // floats: [0..63] = 32 doubles, [64] = band count (uint32 bits)
-constexpr int kContribCap = 512;                       // band records per rank
-constexpr int kContribFloats = kContribHdr + kContribCap * 32;
+__host__ __device__ __forceinline__ int contrib_cap_for(int n_ranks) {
+    return n_ranks <= 1 ? 8192 : (n_ranks == 2 ? 4096 : (n_ranks <= 4 ? 2048 : (n_ranks <= 8 ? 1024 : 512)));
+}
+__host__ __device__ __forceinline__ size_t contrib_floats(int cap) { return (size_t)kContribHdr + (size_t)cap * 32; }
 constexpr int kAccRows = 64;   // replicas of the 32-double accumulator (spreads the fp64 atomics)
 constexpr int kRec = 32;   // floats per band record
 // Band buffer layout: record-major band[slot][kRec] (component-major, with or without a padded pitch, measured

@@ -90,6 +90,8 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
                 unsigned long long seq, int fused, const float* __restrict__ band, float* __restrict__ w_out,
                 const SelectState* __restrict__ sel, const float* __restrict__ gathered, int n_ranks, int my_rank,
                 XicpState* __restrict__ xs) {
+    const int contrib_cap = contrib_cap_for(n_ranks);              // gathered blocks: per-rank record capacity
+    const size_t contrib_stride = contrib_floats(contrib_cap);     // floats per rank block
     // fused: 0 = select-based iteration, 1 = fused iteration (band verification), 2 = R8x finish: the sums are
     // already in the state (first-iteration localizability analysis done in between), only solve + update
     const bool finish = fused == 2;
@@ -159,9 +161,9 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
             uint32_t off = 0, bad = 0;
             for (int r = 0; r < n_ranks; ++r) {
                 rk_off[r] = off;
-                const uint32_t cnt = reinterpret_cast<const uint32_t*>(gathered + (size_t)r * kContribFloats)[64];
-                if (cnt > (uint32_t)kContribCap) bad = 1;
-                off += min(cnt, (uint32_t)kContribCap);
+                const uint32_t cnt = reinterpret_cast<const uint32_t*>(gathered + (size_t)r * contrib_stride)[64];
+                if (cnt > (uint32_t)contrib_cap) bad = 1;
+                off += min(cnt, (uint32_t)contrib_cap);
             }
             rk_off[n_ranks] = off;
             rk_bad = bad;
@@ -176,7 +178,7 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
         if (!gathered) return band[band_at(c, i)];
         int r = 0;
         while (r + 1 < n_ranks && i >= rk_off[r + 1]) ++r;
-        return gathered[(size_t)r * kContribFloats + kContribHdr + (size_t)(i - rk_off[r]) * kRec + c];
+        return gathered[(size_t)r * contrib_stride + kContribHdr + (size_t)(i - rk_off[r]) * kRec + c];
     };
     // fused path: issue this thread's band-record loads right away (they only depend on the record count); the
     // barriers below are LDS-only, so the loads stay in flight behind the partial sums
@@ -209,7 +211,7 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
     }
     if (gathered) {
         for (int r = part; r < n_ranks; r += 32)
-            t += reinterpret_cast<const double*>(gathered + (size_t)r * kContribFloats)[comp];
+            t += reinterpret_cast<const double*>(gathered + (size_t)r * contrib_stride)[comp];
     } else if (fused) {
         for (int b = part; b < kAccRows; b += 32)
             const_cast<double*>(partials)[(size_t)b * kSums + comp] = 0.0;   // ready for the next iteration
