@@ -41,7 +41,10 @@ class Result(C.Structure):
 
 
 def build(force: bool = False) -> str:
-    """Compile the oracle with gcc (seconds).  Returns the .so path."""
+    """Compile the oracle with gcc (seconds).  Returns the .so path.  O3D_ORACLE_LIB points the tests at another build of
+    the same source (the ASan / UBSan build of tools/oracle_sanitizers.sh)."""
+    if os.environ.get("O3D_ORACLE_LIB"):
+        return os.environ["O3D_ORACLE_LIB"]
     src = os.path.join(_HERE, "icp_oracle.c")
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-B", "_build/libicp_oracle.so"], stdout=subprocess.DEVNULL)
@@ -54,8 +57,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        build()
-        _lib = C.CDLL(_SO)
+        _lib = C.CDLL(build())
         _lib.orc_kd_build.restype = C.c_void_p
         _lib.orc_kd_build.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
         _lib.orc_kd_free.argtypes = [C.c_void_p]
