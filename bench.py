@@ -180,8 +180,8 @@ def pmc_traffic(workload, dom):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
                     help="default: c3 on one GPU, c4 (200k -> 20M, reading split over the ranks) on N > 1")
     ap.add_argument("--mode", default="strong", choices=("strong", "weak"),
