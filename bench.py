@@ -301,6 +301,21 @@ def main():
     achieved = n_local * bytes_pp / (kern[dom]["avg_ms"] * 1e-3) / 1e9
     traffic, traffic_src = pmc_traffic(workload, dom) if not multi else (None, None)
 
+    # ---- N > 1: the SAME workload (whole reading, same map) on rank 0's GPU alone, plain single-GPU loop: the denominator
+    #      of an honest strong-scaling figure (N = 1 of this script is the C3 headline, a different workload)
+    single = None
+    if multi and rank == 0:
+        ds1 = DeviceScene(torch, dev, sc)
+        r1 = ds1.make_reg(capi, chain_params(capi, local_rank))
+        s_steps = max(3, args.steps // 4)
+        t1, (T1, _res1) = time_registrations(torch, r1, T_init, s_steps)
+        single = {"value": ITERS * s_steps / t1, "unit": "iter/s", "ms_per_registration": 1e3 * t1 / s_steps,
+                  "n_source": int(sc.src_xyz.shape[0]), "same_pose_as_group": bool(np.array_equal(T1, T_final)),
+                  "note": "whole reading against the same map on ONE GPU (reg_register), timed after the group's run"}
+        r1.close()
+        del ds1
+        torch.cuda.empty_cache()
+
     # ---- secondary objects (single GPU only; never `value`) ----
     extras = {}
     if not multi and not args.no_extras:
@@ -451,6 +466,10 @@ def main():
             "band_stalls_last_step": int(res_final.n_band_stalls) if not multi else None,
         }
         line.update(extras)
+        if single is not None:
+            line["single_gpu_same_workload"] = single
+            # whole-reading iterations/s of the group over those of one GPU
+            line["speedup_vs_single_gpu_same_workload"] = (value / world if scaling == "weak" else value) / single["value"]
         if not args.no_cpu_baseline:
             cores = os.cpu_count() or 1
             threads = min(cores, 64)
