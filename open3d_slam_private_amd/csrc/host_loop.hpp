@@ -551,10 +551,10 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
         const int completed = any ? mir->iterations : 0;
         const int inflight = (int)(h->seq - acked);
         if (completed + inflight < limit && inflight < kAhead) {
-            // fuse once the trimmed limit is settling (last two limits the host has seen within 25 %): by the time the
-            // first fused iteration runs, the lookahead has put two more iterations in between, and its band comes from
-            // the device's latest pair of limits anyway -- narrow (few hundred records), practically never mispredicted
-            // (measured on three scenes: 5 % / 25 % / 50 % / none: no stalls, 25 % fastest by 1-3 %)
+            // fuse once the trimmed limit has settled (last two limits the host has seen within settle_tol, 5 %): the first
+            // fused iteration is the expensive one -- its band is as wide as the limit still moves (wide band -> histogram
+            // select in the update kernel, many coherence failures) -- so starting too early costs more than another
+            // select-based iteration (round-2 sweep, DESIGN.md 6.0: 25 % -> 5 %: C3 1.653 -> 1.574 ms)
             bool settled = true;
             if (trimming) {
                 settled = any && mir->limit_prev < INFINITY && mir->limit_last < INFINITY &&

@@ -178,9 +178,9 @@ class FusedStreamDistributedRegistration(StreamDistributedRegistration):
         super().__init__(reg, use_trimmed, iters, dist=dist, device=device, all_reduce=all_reduce)
         import torch
         self.world, self.rank, self.fixed, self.settle_tol, self.timeout_s = world, rank, fixed, settle_tol, timeout_s
-        # settle_tol: stricter than the single-GPU loop's 25 % -- a rank's contribution block holds a bounded number of band
-        # records (contrib_cap_for(world) in kernels_fused.hpp), and the band of the first fused iterations is as wide as the limit still moves (measured: at 25 % the
-        # first fused iteration overflowed the block, stalled, and the whole burst behind it ran as no-ops)
+        # settle_tol: a rank's contribution block holds a bounded number of band records (contrib_cap_for(world) in
+        # kernels_fused.hpp), and the band of the first fused iterations is as wide as the limit still moves (measured: at
+        # 25 % the first fused iteration overflowed the block, stalled, and the whole burst behind it ran as no-ops)
         # select-by-gather: ONE all-gather of the squared distances instead of three dependent histogram all-reduces
         # per select-based iteration (every rank then runs the exact select on the same multiset of values)
         self.gather_select = bool(gather_select) and bool(use_trimmed)
