@@ -35,6 +35,7 @@ struct DevBuf {
 struct EnvSwitches {
     bool trace = false;         // O3D_TRACE: host-side timeline of prepare / enqueue / reports on stderr
     bool event_timing = false;  // O3D_EVENT_TIMING: loop_ms from HIP events even when not profiling
+    bool no_dynprune = false;   // O3D_NO_DYNPRUNE: level scans keep the ball they started with (A/B)
     bool no_burst = false;      // O3D_NO_BURST: trickle-feed the fused iterations (A/B of the burst submission)
     bool hints = false;         // O3D_HINTS: histogram of the terminating search level of the last iteration
     bool stamps = false;        // O3D_STAMPS: in-kernel cycle stamps of the update kernel
@@ -52,6 +53,7 @@ struct EnvSwitches {
         trace = getenv("O3D_TRACE") != nullptr;
         event_timing = getenv("O3D_EVENT_TIMING") != nullptr;
         no_burst = getenv("O3D_NO_BURST") != nullptr;
+        no_dynprune = getenv("O3D_NO_DYNPRUNE") != nullptr;
         hints = getenv("O3D_HINTS") != nullptr;
         stamps = getenv("O3D_STAMPS") != nullptr;
         coh_stats = getenv("O3D_COH_STATS") != nullptr;
@@ -430,6 +432,7 @@ static reg_status build_grid(reg_handle* h, float c, const float bmin[3], const 
                                                        use_rows ? h->t_rows.as<unsigned long long>() : nullptr);
     g.brick_dir = use_dir ? h->t_dir.as<int32_t>() : nullptr;
     g.brick_rows = use_rows ? h->t_rows.as<unsigned long long>() : nullptr;
+    g.dyn_prune = h->env.no_dynprune ? 0 : 1;
     g.bdx = bdx;
     g.bdy = bdy;
     g.bdz = bdz;

@@ -60,6 +60,7 @@ struct Grid {
     // when that x-row of 8 bins holds at least one point.  A bin box of a large radius is mostly empty rows (a surface
     // crosses ~n of the n^2 rows of a brick): the wide level scan enumerates only the set bits.
     const unsigned long long* brick_rows;
+    int dyn_prune;   // 1: the ball of a level scan shrinks with the group's running best (O3D_NO_DYNPRUNE: A/B)
 };
 
 struct Xf {  // row-major 3x4
@@ -468,8 +469,8 @@ __device__ __forceinline__ float scan_level_rows(const Grid& g, const float3 p, 
     constexpr float kPruneSlack = 4e-3f;
     const bool prune = kPrune && g.dimx <= 8192 && g.dimy <= 8192 && g.dimz <= 8192;
     const float fxq = (p.x - g.ox) * g.inv_c, fyq = (p.y - g.oy) * g.inv_c, fzq = (p.z - g.oz) * g.inv_c;
-    const float rbb = rb * g.inv_c + kPruneSlack;
-    const float rb2 = rbb * rbb;
+    float rbb = rb * g.inv_c + kPruneSlack;
+    float rb2 = rbb * rbb;
     for (int cb = 0; cb < n_bricks; cb += G) {
         // ---- this lane's brick of the chunk: directory entry + row mask (one batch of independent loads)
         const int bi = cb + sub;
@@ -504,6 +505,25 @@ __device__ __forceinline__ float scan_level_rows(const Grid& g, const float3 p, 
         if (total == 0) continue;
         const uint32_t excl = incl - cnt;
         for (int base = 0; base < total; base += CAP) {
+            if (prune && g.dyn_prune && g.rho[l] < INFINITY) {
+                // The ball shrinks with the best candidate the GROUP has seen so far (the box was sized before the level
+                // started; rows come in brick order, not by distance): same rule as the candidate-bounded box above -- no
+                // point farther than a known candidate can win, ties stay inside -- so the rows still to come are cut to
+                // the ball of the current best.  The covered radius shrinks with it.
+                float gb = best.d2;
+#pragma unroll
+                for (int o = G / 2; o >= 1; o >>= 1) gb = fminf(gb, __shfl_xor(gb, o));
+                if (gb < INFINITY) {
+                    const float dc = __builtin_amdgcn_sqrtf(gb) + slack;
+                    const float rs = dc * 1.001f + (g.rho_box[l] - g.rho[l]);
+                    if (rs < rb) {
+                        rb = rs;
+                        cover = fminf(cover, dc);
+                        rbb = rb * g.inv_c + kPruneSlack;
+                        rb2 = rbb * rbb;
+                    }
+                }
+            }
             // phase 1: this lane's row segments of the batch -> bin starts (independent loads)
             uint32_t s[S], e[S];
 #pragma unroll
