@@ -47,6 +47,7 @@ struct EnvSwitches {
     float halo_rho = 0.4f;      // O3D_HALO_RHO: exactness radius of the halo level in units of the halo-bin edge (round 2 sweep,
                                 // profiles/r02_table_sweep.txt: 0.4 beats 0.25 by 2-6 % on C2 / C3 / C4 -- fewer queries fall through
                                 // to the level scans, whose latency chain bounds the search kernels)
+    float reach_bins = 7.25f;   // O3D_REACH_BINS: the automatic bin edge is at least max_dist / this
     float bin_occupancy = 8.f;  // O3D_BIN_OCC: points per occupied bin the automatic bin edge aims at
     float level_ratio = 2.0f;   // O3D_LEVEL_RATIO: ratio of consecutive search radii (c/2, ... up to max_dist)
     void read() {
@@ -61,6 +62,7 @@ struct EnvSwitches {
         if (const char* v = getenv("O3D_SETTLE")) settle_tol = (float)atof(v);
         if (const char* v = getenv("O3D_HALO_RATIO")) halo_ratio = std::min(4.0f, std::max(0.5f, (float)atof(v)));
         if (const char* v = getenv("O3D_HALO_RHO")) halo_rho = std::min(1.0f, std::max(0.05f, (float)atof(v)));
+        if (const char* v = getenv("O3D_REACH_BINS")) reach_bins = std::max(1.0f, (float)atof(v));
         if (const char* v = getenv("O3D_BIN_OCC")) bin_occupancy = std::min(64.0f, std::max(1.0f, (float)atof(v)));
         if (const char* v = getenv("O3D_LEVEL_RATIO")) level_ratio = std::min(4.0f, std::max(1.2f, (float)atof(v)));
     }
@@ -666,7 +668,7 @@ static reg_status set_target_impl(reg_handle* h, const float* xyz, int64_t xyz_s
         // A bin box of the largest radius should not span more than ~15 bins per axis: the early iterations of a registration
         // search with radii up to max_dist, and their cost grows with the number of rows in the box (measured at 20 M points:
         // 0.050 m bins 3.48 ms per registration, 0.069 m bins 3.27 ms).
-        const float cs_reach = (std::isfinite(h->prm.max_dist) && !h->structure_only) ? h->prm.max_dist / 7.25f : 0.f;
+        const float cs_reach = (std::isfinite(h->prm.max_dist) && !h->structure_only) ? h->prm.max_dist / h->env.reach_bins : 0.f;
         if (cs < cs_reach) {
             cs = cs_reach;
             const reg_status s = build(cs);
