@@ -1041,3 +1041,34 @@ def test_coherence_shortcut_with_halo_radius_beyond_max_dist(max_dist, cell, use
     for T, it, ids, d2, w in outs[1:]:
         assert it == itg and np.array_equal(T, Tg)
         assert np.array_equal(ids, idsg) and np.array_equal(d2.view(np.uint32), d2g.view(np.uint32)) and np.array_equal(w, wg)
+
+
+def test_many_registrations_on_one_handle_fused_equals_select_based():
+    """Soak in miniature (tools/tools_soak.py): one handle, changing maps / reading slices / priors, checker mode; every
+    registration is repeated on a handle with the fused path off and must give the same pose bit for bit (the per-point
+    cache, the queues and the band state carry nothing over from one registration to the next)."""
+    rng = np.random.default_rng(77)
+    scenes = [synth.make_scene(12000, 120000, seed=s) for s in (31, 32)]
+    p = capi.shipped_params()
+    q = capi.shipped_params()
+    q.disable_fused = 1
+    reg, ref = capi.Registration(p), capi.Registration(q)
+    for i in range(60):
+        if i % 20 == 0:
+            sc = scenes[(i // 20) % 2]
+            reg.set_target(sc.tgt_xyz, sc.tgt_nrm)
+            ref.set_target(sc.tgt_xyz, sc.tgt_nrm)
+        lo = int(rng.integers(0, 4000))
+        hi = int(rng.integers(lo + 2000, 12000))
+        scale = float(rng.choice([0.002, 0.01, 0.05]))
+        T0 = np.eye(4, dtype=np.float32)
+        T0[:3, :3] = synth.rpy_to_R(*rng.normal(scale=scale, size=3))
+        T0[:3, 3] = rng.normal(scale=5 * scale, size=3)
+        for r in (reg, ref):
+            r.set_source(sc.src_xyz[lo:hi], sc.src_nrm[lo:hi])
+        T, res = reg.register(T0)
+        T2, res2 = ref.register(T0)
+        assert np.array_equal(T, T2) and res.iterations == res2.iterations, (i, res.iterations, res2.iterations)
+        assert res.n_inliers == res2.n_inliers
+    reg.close()
+    ref.close()
