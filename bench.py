@@ -329,6 +329,27 @@ def main():
                           "n_constraints": int(xres.n_constraints),
                           "same_pose_as_plain_chain": bool(np.array_equal(Tx, T_final))}
         xreg.close()
+        # (1b) the GICP cost (the north star's cost function; parity unpinned) on the headline clouds
+        if True:
+            tcov = torch.from_numpy(sc.tgt_cov).to(dev)
+            scov = torch.from_numpy(np.ascontiguousarray(sc.src_cov[lo:hi])).to(dev)
+            pgh = capi.default_params()
+            pgh.cost = capi.COST_GICP
+            pgh.use_trimmed = 0
+            pgh.max_dist = 0.5
+            pgh.fixed_iters = ITERS
+            pgh.device = local_rank
+            gh = capi.Registration(pgh)
+            gh.set_target_device(ds.tgt.data_ptr(), 3, n_tgt, None, 3, tcov.data_ptr())
+            gh.set_source_device(ds.src.data_ptr(), 3, n_local, None, 3, scov.data_ptr())
+            tgh, (Tgh, _gres) = time_registrations(torch, gh, T_init, x_steps)
+            ght, ghr = synth.pose_error(Tgh, sc.T_true)
+            extras["gicp_headline_clouds"] = {"value": ITERS * x_steps / tgh, "unit": "iter/s",
+                                              "ms_per_registration": 1e3 * tgh / x_steps, "workload": workload,
+                                              "pose_vs_truth": {"trans_m": ght, "rot_rad": ghr}}
+            gh.close()
+            del tcov, scov
+            torch.cuda.empty_cache()
         if workload != "tiny":
             # (2) C2 (BASELINE configs[1]): 100k -> 1M
             n2, m2, s2 = WORKLOADS["c2"]
