@@ -199,8 +199,8 @@ static reg_status dist_fail(reg_handle* h, const std::string& what) {
 
 static reg_status dist_all_reduce(reg_handle* h, void* buf, int64_t count, int dtype) {
     DistCtx* d = h->dist;
-    if (d->n_ranks == 1) return REG_OK;
-    if (d->use_rccl) {
+    if (d->n_ranks == 1 && !d->use_rccl) return REG_OK;
+    if (d->use_rccl) {   // also with ONE rank: the call sequence of the N > 1 loop is then what a one-GPU box exercises
         const ncclDataType_t t = dtype == REG_DT_I32 ? ncclUint32 : (dtype == REG_DT_I64 ? ncclInt64 : ncclFloat64);
         const ncclResult_t r = g_rccl.AllReduce(buf, buf, (size_t)count, t, ncclSum, d->comm, h->stream);
         if (r != ncclSuccess) return dist_fail(h, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error"));
@@ -213,7 +213,7 @@ static reg_status dist_all_reduce(reg_handle* h, void* buf, int64_t count, int d
 
 static reg_status dist_all_gather(reg_handle* h, const void* send, void* recv, int64_t bytes_per_rank) {
     DistCtx* d = h->dist;
-    if (d->n_ranks == 1) {
+    if (d->n_ranks == 1 && !d->use_rccl) {
         HIPCHK(h, hipMemcpyAsync(recv, send, (size_t)bytes_per_rank, hipMemcpyDeviceToDevice, h->stream));
         return REG_OK;
     }
