@@ -329,6 +329,17 @@ def main():
                           "n_constraints": int(xres.n_constraints),
                           "same_pose_as_plain_chain": bool(np.array_equal(Tx, T_final))}
         xreg.close()
+        # (1a) the shipped chain as the mapper runs it: its own transformation checkers decide when to stop
+        #      (Differential 0.001 / 0.008 / 3, Counter 30) instead of the metric's fixed 20 iterations
+        pc = capi.shipped_params()
+        pc.device = local_rank
+        creg = ds.make_reg(capi, pc)
+        tc, (Tc, cres) = time_registrations(torch, creg, T_init, x_steps)
+        ct, cr = synth.pose_error(Tc, sc.T_true)
+        extras["shipped_checkers"] = {"ms_per_registration": 1e3 * tc / x_steps, "iterations": int(cres.iterations),
+                                      "iter_per_s": int(cres.iterations) * x_steps / tc, "workload": workload,
+                                      "converged": bool(cres.converged), "pose_vs_truth": {"trans_m": ct, "rot_rad": cr}}
+        creg.close()
         # (1b) the GICP cost (the north star's cost function; parity unpinned) on the headline clouds
         if True:
             tcov = torch.from_numpy(sc.tgt_cov).to(dev)
