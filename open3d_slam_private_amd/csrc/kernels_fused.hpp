@@ -480,7 +480,7 @@ k_coh_check(const float4* __restrict__ src, const float4* __restrict__ src_nrm, 
 }
 
 template <int G>
-__global__ void __launch_bounds__(256, O3D_MATCH_WAVES)
+__global__ void __launch_bounds__(256, O3D_SEARCH_WAVES)
 k_coh_search(const float4* __restrict__ src, const float4* __restrict__ src_nrm, int64_t n, IterState* __restrict__ it,
              Grid g, const float4* __restrict__ tgt_nrm, FilterCfg f, int* __restrict__ pos_io, float* __restrict__ d2_out,
              float* __restrict__ w_out, uint8_t* __restrict__ hint, float4* __restrict__ cache,

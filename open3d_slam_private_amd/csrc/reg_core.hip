@@ -27,6 +27,9 @@ using namespace o3dreg;
 #ifndef O3D_MATCH_WAVES
 #define O3D_MATCH_WAVES 1
 #endif
+#ifndef O3D_SEARCH_WAVES
+#define O3D_SEARCH_WAVES O3D_MATCH_WAVES
+#endif
 
 #include "reg_state.hpp"
 #include "kernels_build.hpp"
