@@ -271,6 +271,9 @@ k_iter_fused(const float4* __restrict__ src, const float4* __restrict__ src_nrm,
 //                 t >> 5); failed points are appended to a queue (one atomic per workgroup).
 //   k_coh_search  fixed grid, grid-stride over the queue in chunks of 32 points: nearest_group with G = 8 lanes per point,
 //                 then the same epilogue and a 32-row LDS table.
+#ifndef O3D_COH_PRUNE
+#define O3D_COH_PRUNE 0
+#endif
 constexpr int kCohRow = 13;   // 12 floats per factor row + 1 pad (bank spread)
 struct CohStats {
     unsigned long long n_points, n_searched;
@@ -531,7 +534,7 @@ k_coh_search(const float4* __restrict__ src, const float4* __restrict__ src_nrm,
             const float3 p2 = xf_point(T, s2.x, s2.y, s2.z);
             int lvl;
             float cov2;
-            const Best bb = nearest_group<G, false, true>(g, p2, sub, -1, &lvl, seg_lds + grp * kSegWords<G>,
+            const Best bb = nearest_group<G, O3D_COH_PRUNE != 0, true>(g, p2, sub, -1, &lvl, seg_lds + grp * kSegWords<G>,
                                                           hv >= 2 ? hv - 2 : -1, &cov2, slack);
             if (sub == 0) {
                 if (hint) hint[qq] = (uint8_t)(lvl + 1);

@@ -399,7 +399,16 @@ __device__ __forceinline__ Best group_min_lazy(const Grid& g, Best b, int gbase)
 // to G * kSegPerLane segments in one flattened pass.  The compacted segment list {first point, exclusive offset}
 // lives in LDS (`seg`: 2 * G * kSegPerLane + 2 words owned by this group); each lane walks it monotonically.
 // Large radii (first iterations of a registration) are bound by dependent-load rounds: this cuts them roughly in half.
-constexpr int kSegPerLane = 4;
+#ifndef O3D_SEG_PER_LANE
+#define O3D_SEG_PER_LANE 4
+#endif
+#ifndef O3D_SCAN_UNROLL
+#define O3D_SCAN_UNROLL 4
+#endif
+#ifndef O3D_HALO_UNROLL
+#define O3D_HALO_UNROLL 4
+#endif
+constexpr int kSegPerLane = O3D_SEG_PER_LANE;
 
 // index of the k-th (0-based) set bit of the 64-bit mask {lo, hi}; k < popcount
 __device__ __forceinline__ int nth_set_bit64(uint32_t lo, uint32_t hi, int k) {
@@ -599,7 +608,7 @@ __device__ __forceinline__ float scan_level_rows(const Grid& g, const float3 p, 
             __builtin_amdgcn_wave_barrier();
             // phase 2: flattened scan, 4 independent 16-byte loads in flight per lane
             uint32_t k = 0, cur_ex = 0, cur_st = seg_st[0], next_ex = seg_ex[1];
-            constexpr int kUnroll = 4;
+            constexpr int kUnroll = O3D_SCAN_UNROLL;
             for (uint32_t f0 = 0; f0 < run_pts; f0 += kUnroll * G) {
                 float4 tv[kUnroll];
                 uint32_t jv[kUnroll];
@@ -663,7 +672,7 @@ __device__ __forceinline__ Best nearest_group(const Grid& g, float3 p, int sub, 
         if (inside) {
             const size_t B = ((size_t)(int)fz * g.hdimy + (int)fy) * g.hdimx + (int)fx;
             const uint32_t s = g.halo_start[B], e = g.halo_start[B + 1];
-            constexpr int kU = 4;
+            constexpr int kU = O3D_HALO_UNROLL;
             for (uint32_t j0 = s; j0 < e; j0 += kU * G) {
                 float4 tv[kU];
 #pragma unroll
