@@ -9,6 +9,7 @@ p = capi.shipped_params(); p.fixed_iters = int(os.environ.get('ITERS', '20'))
 if os.environ.get('CELL'): p.cell_size = float(os.environ['CELL'])
 if os.environ.get('XICP'): p.use_xicp = 1
 if os.environ.get('DBG'): p.debug_flags = int(os.environ['DBG'])
+if os.environ.get('DBGF'): p.disable_fused = int(os.environ['DBGF'])
 if os.environ.get('TRACE_LAST'):
     os.environ['O3D_TRACE'] = '1'   # switches are read when the handle is created: every registration is traced
 reg = capi.Registration(p)
