@@ -35,6 +35,7 @@ struct DevBuf {
 struct EnvSwitches {
     bool trace = false;         // O3D_TRACE: host-side timeline of prepare / enqueue / reports on stderr
     bool event_timing = false;  // O3D_EVENT_TIMING: loop_ms from HIP events even when not profiling
+    bool halo_occ = true;       // O3D_NO_HALO_OCC: halo-bin edge from the floored bin edge instead of the density-derived one (A/B)
     bool no_dynprune = false;   // O3D_NO_DYNPRUNE: level scans keep the ball they started with (A/B)
     bool no_burst = false;      // O3D_NO_BURST: trickle-feed the fused iterations (A/B of the burst submission)
     bool hints = false;         // O3D_HINTS: histogram of the terminating search level of the last iteration
@@ -55,6 +56,7 @@ struct EnvSwitches {
         event_timing = getenv("O3D_EVENT_TIMING") != nullptr;
         no_burst = getenv("O3D_NO_BURST") != nullptr;
         no_dynprune = getenv("O3D_NO_DYNPRUNE") != nullptr;
+        halo_occ = getenv("O3D_NO_HALO_OCC") == nullptr;
         hints = getenv("O3D_HINTS") != nullptr;
         stamps = getenv("O3D_STAMPS") != nullptr;
         coh_stats = getenv("O3D_COH_STATS") != nullptr;
@@ -638,6 +640,7 @@ static reg_status set_target_impl(reg_handle* h, const float* xyz, int64_t xyz_s
     // bin edge: user value, or adapt to ~8 points per occupied bin (surface-like clouds: count ~ c^2)
     float cs = h->prm.cell_size;
     uint32_t occupied = 0;
+    float cs_occ = 0.f;   // automatic edge before the reach floor (0: explicit cell_size)
     if (cs > 0.f) {
         reg_status s = build_grid(h, cs, bmin, bmax, &occupied);
         if (s != REG_OK) return s;
@@ -669,6 +672,7 @@ static reg_status set_target_impl(reg_handle* h, const float* xyz, int64_t xyz_s
         // search with radii up to max_dist, and their cost grows with the number of rows in the box (measured at 20 M points:
         // 0.050 m bins 3.48 ms per registration, 0.069 m bins 3.27 ms).
         const float cs_reach = (std::isfinite(h->prm.max_dist) && !h->structure_only) ? h->prm.max_dist / h->env.reach_bins : 0.f;
+        cs_occ = cs;
         if (cs < cs_reach) {
             cs = cs_reach;
             const reg_status s = build(cs);
@@ -686,7 +690,10 @@ static reg_status set_target_impl(reg_handle* h, const float* xyz, int64_t xyz_s
     h->grid.pts = h->t_pts.as<float4>();
     set_levels(h, cs, max_abs);
     {
-        reg_status hs = build_halo(h, cs, bmin, bmax, max_abs);
+        // The halo bins serve the settled searches (neighbours a few centimetres away): their edge follows the DENSITY of the
+        // map, not the reach floor of the level grid (20 M points: runs of ~170 points with 0.10 m halo bins, ~90 with 0.075 m)
+        const float c_halo = (h->env.halo_occ && cs_occ > 0.f) ? std::min(cs, cs_occ) : cs;
+        reg_status hs = build_halo(h, c_halo, bmin, bmax, max_abs);
         if (hs != REG_OK) return hs;
     }
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
