@@ -185,21 +185,20 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
     const bool trim = s_use_trim && s_ratio != 1.0f;
     const uint32_t n_band = (fused && trim && !band_bad) ? s_band_count : 0u;
     const bool add_comp = comp != 29 && comp != 31;
-    float pre[16];
-    uint32_t my_d2[kBandCap / 1024];
+    // Registers hold what the USUAL band needs (<= 1024 records' d2, the first kPre * 32 records' components): the first
+    // fused iterations' larger bands take the loops further down (the kernel sits on the 128-register cap of its 1024-thread
+    // workgroup; every array kept live across it ends up in scratch on the common path).
+    constexpr int kPre = 8;
+    float pre[kPre];
+    uint32_t my_d2[1];
     if (n_band) {
+        my_d2[0] = 0u;
+        if (spec)
+            my_d2[0] = spec_d2;
+        else if (threadIdx.x < n_band)
+            my_d2[0] = __float_as_uint(rec(threadIdx.x, 29));
 #pragma unroll
-        for (int u = 0; u < kBandCap / 1024; ++u) {
-            my_d2[u] = 0u;
-            if (u == 0 && spec) {
-                my_d2[0] = spec_d2;
-            } else if (1024u * u < n_band) {   // workgroup-uniform: a band of a few hundred records issues one load, not 16
-                const uint32_t i = threadIdx.x + 1024u * u;
-                if (i < n_band) my_d2[u] = __float_as_uint(rec(i, 29));
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < kPre; ++u) {
             pre[u] = 0.f;
             if (u < kSpec && spec) {
                 pre[u] = spec_pre[u < kSpec ? u : 0];
@@ -259,12 +258,9 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
             return;
         }
         if (n_finite != 0) {
-            // stage the band's d2 bit patterns (loaded at kernel start) in LDS
-#pragma unroll
-            for (int u = 0; u < kBandCap / 1024; ++u) {
-                const uint32_t i = threadIdx.x + 1024u * u;
-                if (1024u * u < n_band && i < n_band) bd2[i] = my_d2[u];
-            }
+            // stage the band's d2 bit patterns in LDS (the first 1024 were loaded at kernel start)
+            if (threadIdx.x < n_band) bd2[threadIdx.x] = my_d2[0];
+            for (uint32_t i = threadIdx.x + 1024u; i < n_band; i += 1024u) bd2[i] = __float_as_uint(rec(i, 29));
             // One-level select: the band's values lie in [band_lo, band_hi), so the order-preserving key
             // (u - u_lo) * 2048 / (u_hi - u_lo) spreads them over 2048 bins (about one value per bin); the bin that
             // holds rank r is then resolved by direct ranking.  Crowded bin (> 64 equal-ish values): radix levels.
@@ -391,11 +387,11 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
             double acc = 0;
             if (add_comp) {
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
+                for (int u = 0; u < kPre; ++u) {
                     const uint32_t i = (uint32_t)part + 32u * u;
                     if (32u * u < n_band && i < n_band && __uint_as_float(bd2[i]) <= limit) acc += (double)pre[u];
                 }
-                for (uint32_t i0 = part + 32u * 16u; i0 < n_band; i0 += 32 * 16) {   // only when n_band > 512
+                for (uint32_t i0 = part + 32u * kPre; i0 < n_band; i0 += 32 * 16) {   // only when n_band > 32 * kPre
                     float vv[16];
 #pragma unroll
                     for (int u = 0; u < 16; ++u) {
