@@ -12,6 +12,7 @@
 #include <limits>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "o3dslam_reg.h"
 
@@ -167,6 +168,7 @@ class SurfaceNormalFilter {
 public:
     unsigned knn = 5;                                             // SurfaceNormal.h:68
     float maxDist = std::numeric_limits<float>::infinity();      // SurfaceNormal.h:69
+    bool smoothNormals = false;                                   // SurfaceNormal.h:76, SurfaceNormal.cpp:259-283
     bool orientTowardsViewpoint = false;                          // CloudRegistration.cpp:37 (camera location)
     std::array<float, 3> viewpoint{{0.f, 0.f, 0.f}};
 
@@ -195,6 +197,13 @@ public:
         out.normals = normals;
         out.eigvals = eigValues;
         out.covs = covariances6;
+        std::vector<int32_t> own_ids;   // smoothNormals needs the neighbour lists even when the caller does not ask for them
+        if (smoothNormals && !matchedIds && !cloud.on_device) {
+            own_ids.resize((size_t)cloud.n * knn);
+            matchedIds = own_ids.data();
+        }
+        if (smoothNormals && !matchedIds)
+            throw InvalidParameter("smoothNormals on device buffers needs a matchedIds buffer (n x knn int32)");
         out.ids = matchedIds;
         out.densities = densities;
         out.mean_dists = meanDists;
@@ -206,6 +215,11 @@ public:
         if (s == REG_BAD_ARGUMENT) throw InvalidParameter(reg_last_error(h_));
         if (s == REG_DEVICE_ERROR) throw DeviceError(reg_last_error(h_));
         if (s != REG_OK) throw std::runtime_error(reg_last_error(h_));
+        if (smoothNormals) {
+            const reg_status t = reg_smooth_normals(h_, normals, matchedIds, cloud.n, (int)knn, cloud.on_device ? 1 : 0, nullptr);
+            if (t == REG_DEVICE_ERROR) throw DeviceError(reg_last_error(h_));
+            if (t != REG_OK) throw std::runtime_error(reg_last_error(h_));
+        }
     }
 
 private:

@@ -352,6 +352,14 @@ REG_API reg_status reg_estimate_normals(reg_handle* h, const float* xyz, int64_t
                                         const reg_normals_out* out, int64_t* n_rescanned);
 
 
+/* SurfaceNormalDataPointsFilter's `smoothNormals` option (SurfaceNormal.cpp:259-283): every normal becomes the mean of its
+   neighbours' normals (those pointing away from it flipped), IN PLACE in index order as the reference does it -- point i
+   reads the already smoothed normals of its lower-indexed neighbours.  normals: n x 3 in / out; ids: n x k as
+   reg_estimate_normals reports them (-1 = no neighbour).  Evaluated on the device as a level-synchronous sweep over the
+   dependency DAG, bit-identical to the sequential loop; n_passes (may be NULL): sweeps launched. */
+REG_API reg_status reg_smooth_normals(reg_handle* h, float* normals, const int32_t* ids, int64_t n, int k, int on_device,
+                                      int32_t* n_passes);
+
 /* ---- next row: target-side preparation on the device ------------------------------------------
    Replaces, in front of reg_set_target, what the mapper does on the host every referenceCloudSettingPeriod_:
      open3d_slam/src/ScanToMapRegistration.cpp:90-96   cropSubmap: scanMatcherCropper_->setPose(mapToRangeSensor); crop(map)

@@ -108,7 +108,7 @@ EXPORTS = ["reg_default_params", "reg_shipped_params", "reg_create", "reg_destro
            "reg_linearize", "reg_get_correspondences", "reg_match_local", "reg_trim_histogram", "reg_reduce_local",
            "reg_solve_update", "reg_host_solve6", "reg_host_x_to_T", "reg_host_centroid", "reg_get_target_info", "reg_profile_kernels", "reg_source_centroid_sums", "reg_prepare_centroid", "reg_compose",
            "reg_dist_begin", "reg_dist_buffers", "reg_dist_phase", "reg_dist_finish",
-           "reg_dist_fused_buffers", "reg_dist_poll", "reg_estimate_normals", "reg_host_solve6_xicp",
+           "reg_dist_fused_buffers", "reg_dist_poll", "reg_estimate_normals", "reg_smooth_normals", "reg_host_solve6_xicp",
            "reg_set_target_f64", "reg_get_target_source_indices", "reg_voxelize_within_volume", "reg_carve_indices", "reg_dist_xicp_buffers", "reg_dist_gather_buffers",
            "reg_dist_record", "reg_dist_centroid_sums", "reg_dist_prepare",
            "reg_information_matrix", "reg_set_source_f64", "reg_debug_configure",
@@ -208,6 +208,7 @@ def load_library():
     lib.reg_information_matrix.argtypes = [vp, f32p, C.c_float, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.reg_dist_xicp_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     lib.reg_dist_gather_buffers.argtypes = [vp, C.c_int, i64, C.POINTER(vp), C.POINTER(vp)]
+    lib.reg_smooth_normals.argtypes = [vp, vp, vp, i64, C.c_int, C.c_int, vp]
     lib.reg_estimate_normals.argtypes = [vp, vp, i64, i64, C.c_int, C.c_int, C.c_float, vp, C.c_int,
                                          C.POINTER(NormalsOut), C.POINTER(C.c_int64)]
     for name in EXPORTS:
@@ -428,6 +429,15 @@ class Registration:
             1 if regularise else 0, C.byref(o), C.byref(resc)))
         out["n_rescanned"] = int(resc.value)
         return out
+
+    def smooth_normals(self, normals, ids):
+        """SurfaceNormalDataPointsFilter's smoothNormals (SurfaceNormal.cpp:259-283) on the device, sequential semantics.
+        Returns (smoothed normals (n,3), sweeps launched)."""
+        nr = np.ascontiguousarray(normals, dtype=np.float32).copy()
+        ii = np.ascontiguousarray(ids, dtype=np.int32)
+        passes = C.c_int32(0)
+        self._check(self._lib.reg_smooth_normals(self._h, _ptr(nr), _ptr(ii), nr.shape[0], ii.shape[1], 0, C.byref(passes)))
+        return nr, int(passes.value)
 
     def estimate_normals_device(self, xyz_ptr, xyz_stride, n, normals_ptr, k=10, max_dist=np.inf, viewpoint=None,
                                 regularise=False, eigvals_ptr=None, covs_ptr=None, ids_ptr=None, eigvecs_ptr=None,

@@ -1068,6 +1068,59 @@ reg_status reg_carve_indices(reg_handle* h, const double* map_xyz, const double*
     return REG_OK;
 }
 
+reg_status reg_smooth_normals(reg_handle* h, float* normals, const int32_t* ids, int64_t n, int k, int on_device,
+                              int32_t* n_passes) {
+    if (!h) return REG_BAD_ARGUMENT;
+    if (!h->device_ok) return REG_DEVICE_ERROR;
+    if (!normals || !ids || k < 1 || k > kPcaMaxK || n > 0x7fffffffLL) {
+        h->err = "reg_smooth_normals: bad argument (normals, ids != NULL, 1 <= k <= 32)";
+        return REG_BAD_ARGUMENT;
+    }
+    if (n <= 0) {
+        h->err = "The point cloud is empty";
+        return REG_EMPTY_SOURCE;
+    }
+    HIPCHK(h, hipSetDevice(h->prm.device));
+    float* d_n = normals;
+    const int32_t* d_i = ids;
+    if (!on_device) {
+        HIPCHK(h, h->n_out.reserve((size_t)n * 12));
+        HIPCHK(h, h->n_ids.reserve((size_t)n * k * 4));
+        HIPCHK(h, hipMemcpyAsync(h->n_out.p, normals, (size_t)n * 12, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->n_ids.p, ids, (size_t)n * k * 4, hipMemcpyHostToDevice, h->stream));
+        d_n = h->n_out.as<float>();
+        d_i = h->n_ids.as<int32_t>();
+    }
+    // work arrays: the original normals, the pass in which a point was finished (-1: not yet), the finished count
+    HIPCHK(h, h->n_extra.reserve((size_t)n * 12 + (size_t)n * 4 + 64));
+    float* orig = h->n_extra.as<float>();
+    int* level = reinterpret_cast<int*>(orig + (size_t)n * 3);
+    unsigned int* n_done = reinterpret_cast<unsigned int*>(level + n);
+    HIPCHK(h, hipMemcpyAsync(orig, d_n, (size_t)n * 12, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipMemsetAsync(level, 0xff, (size_t)n * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(n_done, 0, 4, h->stream));
+    int pass = 0;
+    unsigned int done = 0;
+    const int batch = 32;   // passes between two looks at the count (finished sweeps are cheap no-ops)
+    while (done < (unsigned int)n) {
+        if ((int64_t)pass > n) {
+            h->err = "reg_smooth_normals: the sweep did not terminate (neighbour ids out of range?)";
+            return REG_BAD_ARGUMENT;
+        }
+        for (int b = 0; b < batch; ++b, ++pass)
+            k_smooth_pass<<<grid_for(n), 256, 0, h->stream>>>(orig, d_n, d_i, n, k, pass, level, n_done);
+        HIPCHK(h, hipMemcpyAsync(&done, n_done, 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    if (n_passes) *n_passes = pass;
+    if (!on_device) {
+        HIPCHK(h, hipMemcpyAsync(normals, d_n, (size_t)n * 12, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    HIPCHK(h, hipGetLastError());
+    return REG_OK;
+}
+
 reg_status reg_estimate_normals(reg_handle* h, const float* xyz, int64_t xyz_stride, int64_t n, int on_device, int k,
                                 float max_dist, const float* viewpoint, int regularise, const reg_normals_out* out,
                                 int64_t* n_rescanned) {

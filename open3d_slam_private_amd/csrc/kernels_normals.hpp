@@ -332,3 +332,52 @@ k_pca_finish(const PcaMoments* __restrict__ mom, int64_t n, float vx, float vy, 
         covs[6 * oi + 5] = (float)Cn[8];
     }
 }
+
+
+// SurfaceNormalDataPointsFilter::smoothNormals (SurfaceNormal.cpp:259-283).  The reference smooths IN PLACE in index order:
+// point i reads the already smoothed normals of its lower-indexed neighbours and the original ones of the others (itself
+// included).  That recurrence is a DAG over the indices; it is evaluated here as a level-synchronous sweep: in pass p a point
+// is computed when every lower-indexed neighbour finished in an EARLIER pass (level < p), with exactly the arithmetic of the
+// sequential loop (fp32, neighbour order of the k-NN list, mean / float(n)).  Passes needed = longest dependency chain + 1
+// (615 on the reference's 25 k-point scan in scan order, ~20 on unordered clouds).
+__global__ void __launch_bounds__(256)
+k_smooth_pass(const float* __restrict__ orig, float* cur, const int32_t* __restrict__ ids, int64_t n, int k, int pass,
+              int* level, unsigned int* __restrict__ n_done) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (level[i] >= 0) return;
+    const int32_t* row = ids + (size_t)i * k;
+    for (int j = 0; j < k; ++j) {
+        const int32_t r = row[j];
+        if (r >= 0 && r < i) {
+            const int lv = level[r];
+            if (lv < 0 || lv >= pass) return;   // not finished before this pass started
+        }
+    }
+    const float c0 = orig[3 * i], c1 = orig[3 * i + 1], c2 = orig[3 * i + 2];
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+    int cnt = 0;
+    for (int j = 0; j < k; ++j) {
+        const int32_t r = row[j];
+        if (r < 0) continue;
+        const float* src = (r < i) ? cur : orig;
+        const float a0 = src[3 * (size_t)r], a1 = src[3 * (size_t)r + 1], a2 = src[3 * (size_t)r + 2];
+        float d = c0 * a0;
+        float t = c1 * a1;
+        d = d + t;
+        t = c2 * a2;
+        d = d + t;
+        if (d > 0.f) {
+            m0 = m0 + a0; m1 = m1 + a1; m2 = m2 + a2;
+        } else {
+            m0 = m0 - a0; m1 = m1 - a1; m2 = m2 - a2;
+        }
+        ++cnt;
+    }
+    const float fn = (float)cnt;
+    cur[3 * i] = m0 / fn;
+    cur[3 * i + 1] = m1 / fn;
+    cur[3 * i + 2] = m2 / fn;
+    level[i] = pass;
+    atomicAdd(n_done, 1u);
+}

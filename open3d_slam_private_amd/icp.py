@@ -216,7 +216,8 @@ class SurfaceNormalDataPointsFilter:
     DataPoints with the `normals` descriptor added (keepNormals) and keeps `eigValues` / `matchedIds` on the filter."""
 
     def __init__(self, knn=5, maxDist=float("inf"), epsilon=0.0, keepNormals=True, keepDensities=False,
-                 keepEigenValues=False, keepEigenVectors=False, keepMatchedIds=False, keepMeanDist=False, viewpoint=None):
+                 keepEigenValues=False, keepEigenVectors=False, keepMatchedIds=False, keepMeanDist=False, viewpoint=None,
+                 smoothNormals=False):
         if knn < 3:
             raise InvalidParameter("knn: minimum 3 (SurfaceNormal.h:68)")
         if knn > 32:
@@ -229,6 +230,7 @@ class SurfaceNormalDataPointsFilter:
         self.keepEigenValues, self.keepMatchedIds, self.viewpoint = keepEigenValues, keepMatchedIds, viewpoint
         self.keepDensities, self.keepEigenVectors, self.keepMeanDist = keepDensities, keepEigenVectors, keepMeanDist
         self.eigValues = self.matchedIds = self.densities = self.eigVectors = self.meanDists = None
+        self.smoothNormals = bool(smoothNormals)   # SurfaceNormal.cpp:259-283 (in place, index order)
         self._reg = None
 
     def filter(self, cloud: DataPoints) -> DataPoints:
@@ -236,12 +238,14 @@ class SurfaceNormalDataPointsFilter:
             self._reg = capi.Registration(capi.default_params())
         try:
             out = self._reg.estimate_normals(cloud.features, k=self.knn, max_dist=self.maxDist, viewpoint=self.viewpoint,
-                                             want_eigvals=self.keepEigenValues, want_ids=self.keepMatchedIds,
+                                             want_eigvals=self.keepEigenValues, want_ids=self.keepMatchedIds or self.smoothNormals,
                                              want_densities=self.keepDensities, want_eigvecs=self.keepEigenVectors,
                                              want_mean_dists=self.keepMeanDist)
+            if self.smoothNormals:
+                out["normals"], _ = self._reg.smooth_normals(out["normals"], out["ids"])
         except RegError as e:
             raise _translate(e) from None
-        self.eigValues, self.matchedIds = out.get("eigvals"), out.get("ids")
+        self.eigValues, self.matchedIds = out.get("eigvals"), (out.get("ids") if self.keepMatchedIds else None)
         self.densities, self.eigVectors, self.meanDists = out.get("densities"), out.get("eigvecs"), out.get("mean_dists")
         return DataPoints(cloud.features, out["normals"] if self.keepNormals else cloud.normals, cloud.covariances)
 

@@ -1607,6 +1607,38 @@ ORC_API void orc_surface_normals(const float* xyz, int64_t stride, int64_t n, in
     orc_kd_free(tree);
 }
 
+/* SurfaceNormalDataPointsFilter::smoothNormals (SurfaceNormal.cpp:259-283): IN PLACE, in index order -- point i reads the
+   ALREADY SMOOTHED normals of its lower-indexed neighbours and the original ones of the others (itself included);
+   neighbours whose normal points away from the point's own (dot <= 0) are flipped; mean / T(n) over the valid matches.
+   normals: n x 3 in / out; ids: n x k, -1 = no match (dists == InvalidDist). */
+ORC_API void orc_smooth_normals(float* normals, const int32_t* ids, int64_t n, int k) {
+    for (int64_t i = 0; i < n; ++i) {
+        const float c0 = normals[3 * i], c1 = normals[3 * i + 1], c2 = normals[3 * i + 2];
+        float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+        int cnt = 0;
+        for (int j = 0; j < k; ++j) {
+            const int32_t r = ids[(size_t)i * k + j];
+            if (r < 0) continue;
+            const float a0 = normals[3 * (size_t)r], a1 = normals[3 * (size_t)r + 1], a2 = normals[3 * (size_t)r + 2];
+            float d = c0 * a0;
+            float t = c1 * a1;
+            d = d + t;
+            t = c2 * a2;
+            d = d + t;
+            if (d > 0.f) {
+                m0 = m0 + a0; m1 = m1 + a1; m2 = m2 + a2;
+            } else {
+                m0 = m0 - a0; m1 = m1 - a1; m2 = m2 - a2;
+            }
+            ++cnt;
+        }
+        const float fn = (float)cnt;
+        normals[3 * i] = m0 / fn;
+        normals[3 * i + 1] = m1 / fn;
+        normals[3 * i + 2] = m2 / fn;
+    }
+}
+
 ORC_API int orc_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

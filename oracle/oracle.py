@@ -401,3 +401,11 @@ def information_matrix(tgt_xyz, src_xyz, T, max_dist):
         G = np.array([[0, z, -y, 1, 0, 0], [-z, 0, x, 0, 1, 0], [y, -x, 0, 0, 0, 1]], np.float64)
         info += G.T @ G
     return info, q.shape[0]
+
+
+def smooth_normals(normals, ids):
+    """SurfaceNormalDataPointsFilter.smoothNormals (SurfaceNormal.cpp:259-283), sequential, in place on a copy."""
+    nr = np.ascontiguousarray(normals, dtype=np.float32).copy()
+    ii = np.ascontiguousarray(ids, dtype=np.int32)
+    lib().orc_smooth_normals(_p(nr), _p(ii), C.c_int64(nr.shape[0]), C.c_int(ii.shape[1]))
+    return nr

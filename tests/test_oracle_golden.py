@@ -278,3 +278,33 @@ def test_oracle_reproduces_the_reference_ref_trans_golden():
     assert rel < 0.05                       # utest.cpp:159
     assert rel < 1e-3, rel                  # what this restatement actually achieves (1.3e-5)
     assert np.abs(T.astype(np.float64) - refT).max() < 5e-4, np.abs(T - refT).max()
+
+
+def test_smooth_normals_oracle_follows_the_in_place_recurrence():
+    """orc_smooth_normals against a line-by-line Python restatement of SurfaceNormal.cpp:259-283 (in place, index order,
+    flipped neighbours, mean / float(n)); fp32 operation by operation."""
+    rng = np.random.default_rng(0)
+    n, k = 300, 6
+    nr = rng.normal(size=(n, 3)).astype(np.float32)
+    nr /= np.linalg.norm(nr, axis=1, keepdims=True)
+    ids = rng.integers(0, n, size=(n, k)).astype(np.int32)
+    ids[rng.random((n, k)) < 0.2] = -1
+    ids[:, 0] = np.arange(n)
+    out = orc.smooth_normals(nr, ids)
+    ref = nr.copy()
+    for i in range(n):
+        c = ref[i].copy()
+        m = np.zeros(3, np.float32)
+        cnt = 0
+        for j in range(k):
+            r = ids[i, j]
+            if r < 0:
+                continue
+            a = ref[r]
+            d = np.float32(np.float32(c[0] * a[0]) + np.float32(c[1] * a[1]))
+            d = np.float32(d + np.float32(c[2] * a[2]))
+            m = (m + a if d > 0 else m - a).astype(np.float32)
+            cnt += 1
+        ref[i] = m / np.float32(cnt)
+    assert np.array_equal(out, ref)
+    assert not np.array_equal(out, nr)
