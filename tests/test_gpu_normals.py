@@ -206,3 +206,49 @@ def test_smooth_normals_equal_the_sequential_in_place_loop():
     raw = SurfaceNormalDataPointsFilter(knn=10, keepMatchedIds=True)
     base = raw.filter(DataPoints(ref))
     assert np.array_equal(out.normals, orc.smooth_normals(base.normals, raw.matchedIds))
+
+
+def test_hybrid_search_normals_follow_open3d_estimate_normals_semantics():
+    """The B1 front end (CloudRegistration.cpp:25-43) calls Open3D 0.15.1 (un-vendored dependency)
+    `EstimateNormals(KDTreeSearchParamHybrid(radius, knn))` + `NormalizeNormals` + `OrientNormalsTowardsCameraLocation()`.
+    Restated here from Open3D's published algorithm (PointCloud::EstimateNormals: the <= knn nearest points within the
+    radius, the point itself included; covariance from double-precision cumulants; eigenvector of the smallest eigenvalue;
+    fewer than 3 neighbours -> (0, 0, 1); flipped to face the camera at the origin) and compared with reg_estimate_normals
+    (knn, max_dist = radius, viewpoint = origin).  Parity unpinned (Open3D is not in the reference tree): same
+    neighbourhoods, normals within 1e-3 rad where the plane is well defined; documented difference: an under-populated
+    neighbourhood yields the zero vector here (libpointmatcher's convention), (0, 0, 1) in Open3D."""
+    from scipy.spatial import cKDTree
+    sc = synth.make_scene(1000, 30000, seed=23)
+    P = sc.tgt_xyz.astype(np.float64)
+    knn, radius = 12, 0.25
+    tree = cKDTree(P)
+    d, idx = tree.query(P, k=knn, distance_upper_bound=radius)
+    reg = capi.Registration(capi.default_params())
+    out = reg.estimate_normals(sc.tgt_xyz, k=knn, max_dist=radius, viewpoint=(0.0, 0.0, 0.0), want_ids=True, want_eigvals=True)
+    reg.close()
+    n_checked = n_under = 0
+    worst = 0.0
+    for i in range(0, P.shape[0], 7):
+        nb = idx[i][np.isfinite(d[i])]
+        mine = out["ids"][i]
+        mine = mine[mine >= 0]
+        assert set(nb.tolist()) == set(mine.tolist()), i            # the hybrid search's neighbourhood
+        if nb.size < 3:
+            n_under += 1
+            assert not out["normals"][i].any()                      # zero vector here, (0, 0, 1) in Open3D
+            continue
+        Q = P[nb]
+        mean = Q.mean(0)
+        C = (Q[:, :, None] * Q[:, None, :]).mean(0) - np.outer(mean, mean)      # cumulants, as Open3D computes them
+        w, V = np.linalg.eigh(C)
+        if w[1] - w[0] < 1e-3 * max(w[2], 1e-12):
+            continue                                                # plane not well defined: direction is ill-conditioned
+        nrm = V[:, 0]
+        if np.dot(nrm, -P[i]) < 0:                                  # OrientNormalsTowardsCameraLocation(origin)
+            nrm = -nrm
+        g = out["normals"][i].astype(np.float64)
+        assert abs(np.linalg.norm(g) - 1.0) < 1e-5                  # NormalizeNormals
+        ang = np.arccos(np.clip(np.dot(nrm, g), -1.0, 1.0))
+        worst = max(worst, ang)
+        n_checked += 1
+    assert n_checked > 500 and worst < 1e-3, (n_checked, worst)
