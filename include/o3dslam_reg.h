@@ -127,6 +127,10 @@ typedef struct {
     float   source_prep_ms;     /* last reg_set_source: upload + Morton order of the reading (device time, HIP events) */
     int32_t rotation_corrected; /* 1: |1 - det R| > 1e-3 in the pre-transform -> points moved with the re-orthogonalised copy
                                    (RigidTransformation::correctParameters, TransformationsImpl.cpp:73-76,105-166) */
+    float   T_iter_prev[16];    /* the T_iter the LAST iteration ran at (column-major, same frames as T_iter_last): the
+                                   correspondences / weights reg_get_correspondences reports belong to this pose */
+    int32_t n_tail_launches;    /* launches of the persistent settled-tail kernel in this registration (0: three-launch path) */
+    int32_t n_tail_iterations;  /* iterations those launches ran */
 } reg_result;
 
 /* ICPChainBase::setDefault (ICP.cpp:100-113): knn 1, eps 0, maxDist inf, Trimmed 0.85,

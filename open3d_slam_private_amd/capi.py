@@ -56,7 +56,8 @@ class RegResult(C.Structure):
                 ("T_iter_last", C.c_float * 16), ("n_band_stalls", C.c_int32), ("n_constraints", C.c_int32),
                 ("prof_ms", C.c_float * 4), ("prof_launches", C.c_int32 * 4), ("localizable", C.c_int32 * 6),
                 ("xicp_combined", C.c_double * 6), ("xicp_high", C.c_double * 6), ("source_prep_ms", C.c_float),
-                ("rotation_corrected", C.c_int32)]
+                ("rotation_corrected", C.c_int32), ("T_iter_prev", C.c_float * 16), ("n_tail_launches", C.c_int32),
+                ("n_tail_iterations", C.c_int32)]
 
 
 class NormalsOut(C.Structure):

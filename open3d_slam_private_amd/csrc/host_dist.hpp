@@ -470,6 +470,7 @@ reg_status reg_dist_finish(reg_handle* h, float T_out[16], reg_result* res) {
     std::memcpy(T_iter, mir->T, 64);
     compose_rowmajor(h, T_iter, Tout_row);
     row_to_col(T_iter, res->T_iter_last);
+    row_to_col(h->h_mirror->T_prev, res->T_iter_prev);
     row_to_col(Tout_row, T_out);
     return REG_OK;
 }

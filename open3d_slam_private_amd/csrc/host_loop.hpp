@@ -342,6 +342,97 @@ static reg_status enqueue_fused(reg_handle* h, bool want_w) {
     return REG_OK;
 }
 
+// ---- persistent settled tail (kernels_tail.hpp): one launch for every remaining iteration -----------------------------
+// Two persistent kernels on one device could each hold a part of the CUs and wait for the other's rest forever, so at most
+// ONE registration per device and process runs its tail this way at a time (try_lock at the start of reg_register: the
+// others -- BASELINE config C5, one registration per HIP stream -- keep the three-launch iteration, which fills the gaps).
+// Across processes every grid barrier of the kernel is bounded (TailCfg::timeout_ticks) and ends in REG_DEVICE_ERROR.
+constexpr int kTailMaxDevices = 64;
+static std::mutex g_tail_mutex[kTailMaxDevices];
+static int g_tail_cus[kTailMaxDevices];          // 0: not probed yet, < 0: the kernel cannot be co-resident on this device
+static std::mutex g_tail_probe_mutex;
+
+struct TailPlan {
+    bool ok = false;
+    int grid = 0, wpc = 0, chunk8 = 0;
+};
+
+// CUs of the device if one k_tail workgroup fits on each (occupancy query), probed once per process and device.
+static int tail_device_cus(int dev) {
+    if (dev < 0 || dev >= kTailMaxDevices) return -1;
+    std::lock_guard<std::mutex> lk(g_tail_probe_mutex);
+    if (g_tail_cus[dev] != 0) return g_tail_cus[dev];
+    int cus = 0, nb = 0;
+    hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tail), hipFuncAttributeMaxDynamicSharedMemorySize, kTailLdsBytes);
+    if (e == hipSuccess)
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k_tail), kTailThreads, kTailLdsBytes);
+    g_tail_cus[dev] = (e == hipSuccess && nb >= 1 && cus >= 8) ? cus : -1;
+    (void)hipGetLastError();
+    return g_tail_cus[dev];
+}
+
+static TailPlan tail_plan(const reg_handle* h) {
+    TailPlan pl;
+    const int cus = tail_device_cus(h->prm.device);
+    if (cus < 8 || h->n <= 0) return pl;
+    int wpc_max = cus / 8;
+    if (h->env.tail_wpc > 0) wpc_max = std::min(wpc_max, h->env.tail_wpc);
+    const int64_t n = h->n;
+    pl.wpc = (int)std::max<int64_t>(1, std::min<int64_t>(wpc_max, (n + 2047) / 2048));
+    pl.chunk8 = (int)((((n + 7) / 8) + 7) / 8 * 8);
+    const int64_t octets = pl.chunk8 / 8, per_wg = (octets + pl.wpc - 1) / pl.wpc * 8;
+    pl.grid = 8 * pl.wpc;
+    pl.ok = per_wg <= kTailSlots;
+    return pl;
+}
+
+static bool tail_eligible(const reg_handle* h) {
+    return h->prm.cost == REG_COST_P2PL && h->dbg.disable_fused != 1 && !(h->dbg.debug_flags & (16 | 64 | 128)) &&
+           h->dbg.lanes_per_point != 4 && !h->env.no_tail && tail_plan(h).ok;
+}
+
+// Enqueue the tail for at most `max_iters` iterations; the kernel reports ONCE (sequence h->seq) when it leaves.
+static reg_status enqueue_tail(reg_handle* h, const TailPlan& pl, int max_iters, bool want_w) {
+    HIPCHK(h, h->i_tail_sync.reserve(kTailSyncWords * 4));
+    HIPCHK(h, h->i_tail_rows.reserve((size_t)2 * pl.grid * kTailRow * 8));
+    HIPCHK(h, h->i_tail_band.reserve((size_t)2 * pl.grid * kTailWgBand * kTailRec * 4));
+    HIPCHK(h, hipMemsetAsync(h->i_tail_sync.p, 0, kTailSyncWords * 4, h->stream));
+    const FilterCfg f = make_filter_cfg(h, 0);
+    TailCfg cfg;
+    cfg.n = h->n;
+    cfg.chunk8 = pl.chunk8;
+    cfg.wpc = pl.wpc;
+    cfg.max_iters = std::max(1, std::min(max_iters, kTailMaxIters));
+    cfg.slack = coherent_slack(h);
+    cfg.seq = ++h->seq;
+    cfg.timeout_ticks = (unsigned long long)(h->env.tail_timeout_s * 1e8);
+    float* w = want_w ? h->i_w.as<float>() : nullptr;
+    uint8_t* hint = h->dbg.match_variant == 2 ? nullptr : h->i_hint.as<uint8_t>();
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool timed = h->profiling && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+    auto args = [&](auto launch) {
+        launch(k_tail, dim3(pl.grid), dim3(kTailThreads), (const float4*)h->s_xyz.as<float4>(),
+               (const float4*)(h->has_snrm ? h->s_nrm.as<float4>() : nullptr), h->i_iter.as<IterState>(), h->grid,
+               (const float4*)h->t_nrm.as<float4>(), f, h->i_pos.as<int>(), h->i_d2.as<float>(), w, hint,
+               (const float4*)h->i_cache.as<float4>(), h->i_tail_sync.as<unsigned>(), h->i_tail_rows.as<double>(),
+               h->i_tail_band.as<float>(), h->d_mirror, cfg);
+    };
+    if (timed) {
+        args([&](auto k, dim3 g, dim3 b, auto... a) { hipExtLaunchKernelGGL(k, g, b, kTailLdsBytes, h->stream, e0, e1, 0, a...); });
+        h->prof_ev.push_back(e0);
+        h->prof_ev.push_back(e1);
+        h->prof_kind.push_back(3);
+    } else {
+        if (e0) (void)hipEventDestroy(e0);
+        args([&](auto k, dim3 g, dim3 b, auto... a) { hipLaunchKernelGGL(k, g, b, kTailLdsBytes, h->stream, a...); });
+    }
+    HIPCHK(h, hipGetLastError());
+    h->have_match = true;
+    return REG_OK;
+}
+
 // One Gauss-Newton iteration worth of kernels (R3-R9), nothing waits on the host.
 static reg_status enqueue_iteration(reg_handle* h, bool want_w) {
     reg_status s = enqueue_match(h);
@@ -524,12 +615,60 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
     const HostMirror* mir = h->h_mirror;
     int generic_left = kGenericFirst;
     const bool trace = h->env.trace;
-    const float settle_tol = h->env.settle_tol;
+    float settle_tol = h->env.settle_tol;
     unsigned long long last_traced = 0;
     const auto t_loop0 = std::chrono::steady_clock::now();
     unsigned long long acked = seq0;   // every sequence <= acked has either reported or been a no-op
     int stalls = 0;
+    // The persistent tail (kernels_tail.hpp) replaces the burst of three-launch fused iterations when this registration
+    // holds the device's tail lock (one persistent kernel per device at a time: see g_tail_mutex).
+    const TailPlan tail_pl = (can_fuse && tail_eligible(h)) ? tail_plan(h) : TailPlan();
+    std::unique_lock<std::mutex> tail_lock;
+    if (tail_pl.ok) {
+        tail_lock = std::unique_lock<std::mutex>(g_tail_mutex[h->prm.device], std::try_to_lock);
+    }
+    const bool use_tail = tail_pl.ok && tail_lock.owns_lock();
+    // The tail kernel copes with a limit that still moves (wide bands cost it a second exchange, not a stall): it takes over as
+    // soon as the predicted band (at most +-60 % around the last limit) can be expected to hold the next one
+    if (use_tail) settle_tol = h->env.tail_settle_tol;
+    unsigned long long tail_seq = 0;   // != 0: a tail launch is in flight; nothing is enqueued behind it
+    h->last_tail_launches = 0;
+    h->last_tail_iters = 0;
     for (;;) {
+        if (tail_seq) {
+            s = wait_seq(h, tail_seq);
+            if (s != REG_OK) return s;
+            const bool reported = mirror_seq(h) >= tail_seq;
+            unsigned words[4] = {0, 0, 0, 0};
+            if (!reported || h->env.coh_stats || mir->status == REG_DEVICE_ERROR)
+                (void)hipMemcpy(words, h->i_tail_sync.as<unsigned>() + kTailErrWord, sizeof(words), hipMemcpyDeviceToHost);
+            if (words[0] != 0 || (reported && mir->status == REG_DEVICE_ERROR)) {
+                h->err = "persistent tail kernel: a grid barrier timed out (workgroups not co-resident? another process "
+                         "running a persistent kernel on this GPU?); set O3D_NO_TAIL=1 to use the three-launch iteration";
+                return REG_DEVICE_ERROR;
+            }
+            if (!reported) acked = h->seq;   // the stream drained without a report: the tail found the loop done / stalled
+            if (h->env.coh_stats)
+                fprintf(stderr, "[o3dreg] tail launch: %u iterations, %u point searches (%.2f %% of the point-iterations)\n", words[2],
+                        words[1], words[2] ? 100.0 * words[1] / ((double)words[2] * (double)h->n) : 0.0);
+            if (reported) h->last_tail_iters += mir->pad3;
+#if O3D_TAIL_STAMPS
+            {
+                unsigned long long st[24];
+                (void)hipMemcpy(st, h->i_tail_sync.as<unsigned>() + kTailStampWord, sizeof(st), hipMemcpyDeviceToHost);
+                const double it_n = std::max(1, reported ? mir->pad3 : 1);
+                static const char* names[12] = {"check", "search", "epilogue", "bandrec+comps", "sum+publish+drain", "arrive+wait", "row sums",
+                                                "band-stage", "band-scan", "band-rank", "band-add", "solve+update"};
+                for (int wg = 0; wg < 2; ++wg) {
+                    fprintf(stderr, "[o3dreg] tail stamps (us per iteration, %s workgroup):", wg ? "last" : "first");
+                    for (int i = 0; i < 12; ++i) fprintf(stderr, " %s %.2f", names[i], st[12 * wg + i] * 0.01 / it_n);
+                    fprintf(stderr, "\n");
+                }
+            }
+#endif
+            tail_seq = 0;
+            continue;
+        }
         const unsigned long long m_seq = std::max(mirror_seq(h), seq0);
         const bool any = m_seq > seq0;
         if (any && mir->done) break;
@@ -565,6 +704,11 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
             if (go_generic) {
                 s = enqueue_iteration(h, true);   // weights are always written: reg_get_correspondences reports them
                 if (generic_left > 0) --generic_left;
+            } else if (use_tail) {
+                // the rest of the registration in ONE launch (it leaves when done, stalled, or out of its iteration budget)
+                s = enqueue_tail(h, tail_pl, limit - (completed + inflight), true);
+                tail_seq = h->seq;
+                ++h->last_tail_launches;
             } else {
                 // Fixed iteration count: nothing the host could learn changes what has to run, so the whole rest of
                 // the registration is submitted in one go (a failed band prediction turns what follows into no-ops
@@ -577,7 +721,7 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
                 const auto tq1 = std::chrono::steady_clock::now();
                 fprintf(stderr, "[o3dreg] t=%.1fus enqueue seq %llu (%s) took %.1fus; mirror at %llu\n",
                         std::chrono::duration<double, std::micro>(tq0 - t_loop0).count(), h->seq - seq0,
-                        go_generic ? "generic" : "fused", std::chrono::duration<double, std::micro>(tq1 - tq0).count(),
+                        go_generic ? "generic" : (use_tail ? "tail" : "fused"), std::chrono::duration<double, std::micro>(tq1 - tq0).count(),
                         std::max(mirror_seq(h), seq0) - seq0);
             }
             if (s != REG_OK) return s;
@@ -662,8 +806,11 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
     std::memcpy(T_iter, mir->T, 64);
     compose_rowmajor(h, T_iter, Tout_row, /*later_kernel_reported=*/true);
     row_to_col(T_iter, res->T_iter_last);
+    row_to_col(mir->T_prev, res->T_iter_prev);
     row_to_col(Tout_row, T_out);
     res->n_band_stalls = h->last_stalls;
+    res->n_tail_launches = h->last_tail_launches;
+    res->n_tail_iterations = h->last_tail_iters;
     rmark("return");
     return REG_OK;
 }

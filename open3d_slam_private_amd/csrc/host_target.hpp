@@ -41,6 +41,10 @@ struct EnvSwitches {
     bool hints = false;         // O3D_HINTS: histogram of the terminating search level of the last iteration
     bool stamps = false;        // O3D_STAMPS: in-kernel cycle stamps of the update kernel
     bool coh_stats = false;     // O3D_COH_STATS: share of the reading points the coherent fused kernel had to search
+    bool no_tail = false;       // O3D_NO_TAIL: three-launch fused iterations instead of the persistent tail kernel (A/B, escape hatch)
+    int tail_wpc = 0;           // O3D_TAIL_WPC: cap on the tail kernel's workgroups per XCD class (0: CUs / 8)
+    float tail_timeout_s = 2.f; // O3D_TAIL_TIMEOUT_S: bound of every grid barrier of the tail kernel
+    float tail_settle_tol = 1.2f; // O3D_TAIL_SETTLE: relative change of the trimmed limit below which the tail kernel takes over
     int lookahead = 2;          // O3D_KAHEAD
     float settle_tol = 0.05f;   // O3D_SETTLE: relative change of the trimmed limit below which the fused iterations start (round 2 sweep:
                                 // 0.05 beats 0.25 by 5 % on C3 -- an early fused iteration has a wide band and moves every point by millimetres)
@@ -60,6 +64,10 @@ struct EnvSwitches {
         hints = getenv("O3D_HINTS") != nullptr;
         stamps = getenv("O3D_STAMPS") != nullptr;
         coh_stats = getenv("O3D_COH_STATS") != nullptr;
+        no_tail = getenv("O3D_NO_TAIL") != nullptr;
+        if (const char* v = getenv("O3D_TAIL_WPC")) tail_wpc = std::max(0, atoi(v));
+        if (const char* v = getenv("O3D_TAIL_SETTLE")) tail_settle_tol = (float)atof(v);
+        if (const char* v = getenv("O3D_TAIL_TIMEOUT_S")) tail_timeout_s = std::min(30.f, std::max(0.01f, (float)atof(v)));
         if (const char* v = getenv("O3D_KAHEAD")) lookahead = std::max(1, atoi(v));
         if (const char* v = getenv("O3D_SETTLE")) settle_tol = (float)atof(v);
         if (const char* v = getenv("O3D_HALO_RATIO")) halo_ratio = std::min(4.0f, std::max(0.5f, (float)atof(v)));
@@ -133,6 +141,8 @@ struct reg_handle {
     DevBuf i_hint, s_keys, s_keys2, s_perm, s_perm2, s_tmp, i_tmpf;
     const uint32_t* perm = nullptr;   // slot -> input index (null: identity)
     int last_stalls = 0;
+    int last_tail_launches = 0, last_tail_iters = 0;   // persistent tail: launches / iterations of the last reg_register
+    DevBuf i_tail_sync, i_tail_rows, i_tail_band;      // persistent tail: counters | per-workgroup sum rows | band records
     unsigned long long dist_seq0 = 0;
     DevBuf d_contrib, d_gathered;     // multi-GPU fused iteration: this rank's block / all ranks' blocks
     int dist_ranks = 0, dist_rank = 0;
@@ -270,7 +280,7 @@ void reg_destroy(reg_handle* h) {
                       &h->t_vals2, &h->t_pts, &h->t_nrm, &h->t_cov, &h->t_flags, &h->t_scan, &h->t_hash, &h->t_cells,
                       &h->t_tmp, &h->t_misc, &h->t_dir, &h->t_rows, &h->s_raw, &h->s_nrm_raw, &h->s_cov_raw, &h->s_xyz, &h->s_nrm, &h->s_cov,
                       &h->s_misc, &h->i_pos, &h->i_d2, &h->i_w, &h->i_hist, &h->i_state, &h->i_partials, &h->i_sums,
-                      &h->i_ids, &h->d_contrib, &h->d_gathered, &h->s_prep, &h->i_iter, &h->t_halo_start, &h->t_halo_cursor, &h->t_halo_pts, &h->i_band, &h->i_acc, &h->i_cache, &h->i_stats, &h->i_queue, &h->i_qcount, &h->i_hint, &h->s_keys, &h->s_keys2, &h->s_perm, &h->s_perm2, &h->s_tmp, &h->i_tmpf};
+                      &h->i_ids, &h->d_contrib, &h->d_gathered, &h->s_prep, &h->i_iter, &h->t_halo_start, &h->t_halo_cursor, &h->t_halo_pts, &h->i_band, &h->i_acc, &h->i_cache, &h->i_stats, &h->i_queue, &h->i_qcount, &h->i_hint, &h->s_keys, &h->s_keys2, &h->s_perm, &h->s_perm2, &h->s_tmp, &h->i_tmpf, &h->i_tail_sync, &h->i_tail_rows, &h->i_tail_band};
     for (DevBuf* b : bufs) b->release();
     if (h->h_mirror) (void)hipHostFree(h->h_mirror);
     if (h->h_iter) (void)hipHostFree(h->h_iter);

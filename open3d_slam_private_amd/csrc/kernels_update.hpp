@@ -556,6 +556,7 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
                 sit->rank_last = rank;
                 x_to_T(x, dT);
                 m4_mul(dT, r_T, Tn);  // T_iter = real * T_iter (ICP.cpp:1213-1215)
+                for (int i = 0; i < 16; ++i) sit->T_prev[i] = r_T[i];
                 for (int i = 0; i < 16; ++i) sit->T[i] = Tn[i];
                 sit->iterations = r_iters + 1;
                 bool iterate;
@@ -582,6 +583,7 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
                         Tn[4 * i + j] = v;
                     }
                 for (int i = 0; i < 16; ++i) {
+                    sit->T_prev[i] = r_T[i];
                     sit->Td[i] = Tn[i];
                     sit->T[i] = (float)Tn[i];
                 }
@@ -605,6 +607,7 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
         // stage the host mirror in LDS (word layout of HostMirror); the whole wave then writes it out
         HostMirror* m = reinterpret_cast<HostMirror*>(mir_w);
         for (int i = 0; i < 16; ++i) m->T[i] = sit->T[i];
+        for (int i = 0; i < 16; ++i) m->T_prev[i] = sit->T_prev[i];
         m->iterations = sit->iterations;
         m->done = sit->done;
         m->status = sit->status;

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -39,6 +40,7 @@ using namespace o3dreg;
 #include "kernels_mapprep.hpp"
 #include "kernels_xicp.hpp"
 #include "kernels_update.hpp"
+#include "kernels_tail.hpp"
 #include "kernels_normals.hpp"
 
 // host side: one handle = one non-re-entrant registration context (include/o3dslam_reg.h)

@@ -7,6 +7,7 @@
 // registration can be enqueued without a host round trip per Gauss-Newton iteration.
 struct IterState {
     float T[16];          // T_iter, row-major (P2PL: centred frames; GICP: reading -> reference)
+    float T_prev[16];     // the pose the last completed iteration RAN at (its matches, weights and sums belong to it)
     double Td[16];        // GICP: the same in double
     Checkers chk;         // DifferentialTransformationChecker / CounterTransformationChecker state
     int iterations;
@@ -54,6 +55,7 @@ struct XicpState {
 struct HostMirror {
     double sums[kSums];
     float T[16];
+    float T_prev[16];
     int iterations, done, status, rank_last, converged, max_iter_reached, stall, band_count;
     float limit_last, limit_prev, band_lo, band_hi;
     int pad_nband, pad2;
