@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: ICP iterations/sec of scan-to-map registration on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|tiny] [--mode strong|weak]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|tiny] [--mode strong|weak|replicas]
 
 A "step" is ONE registration of the synthetic scan against the synthetic map with exactly ITERS (=20) Gauss-Newton
 iterations of the reference's chain (param/icp.yaml: knn 1, maxDist 0.5, TrimmedDist 0.9, SurfaceNormal 1.57,
@@ -20,6 +20,12 @@ N > 1: workload C4 as BASELINE.json states it: ONE 200k-point reading split into
         the 32-double (H, b, e, counts) record over RCCL.  STRONG scaling: `value` = ITERS * K / t, whole-reading
         iterations per second.  `--mode weak` (explicit) keeps the reading at 200k points PER RANK instead.
 
+--mode replicas (any N): BASELINE.json configs[4] -- 64 independent C2-shaped registrations (seed + i), 64 / N per rank, 8 in
+        flight per GPU (one handle + HIP stream + host thread each), NO collectives; a "step" is one pass over the 64
+        registrations, `value` the aggregate ICP iterations/s of all ranks; every timed pose is checked against the same
+        problem registered alone on its GPU afterwards.  WEAK scaling (per-GPU work is fixed at 64 / N ... of a fixed batch:
+        "strong" in the batch, reported as such).
+
 Prints ONE JSON line (rank 0).
 """
 import argparse
@@ -36,11 +42,13 @@ sys.path.insert(0, ROOT)
 ITERS = 20
 WORKLOADS = {"c2": (100_000, 1_000_000, 1234 + 2), "c3": (200_000, 5_000_000, 1234 + 3),
              "c4": (200_000, 20_000_000, 1234 + 4), "tiny": (10_000, 100_000, 1234 + 1)}
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_MEASURED_GBS = 6290.0   # ... and 6.29 TB/s measured (float4 copy): the secondary denominator SURVEY 8d asks for
 # algorithmic bytes per reading point and launch:
 #   k_match_g8  : src xyz 12 + matched tgt xyz 12 + pos 4 + d2 4 written            = 32
 #   fused_pair  : src xyz 12 + src normal 12 + matched tgt xyz 12 + tgt normal 12 (P2Pl) = 48
 #                 (k_coh_check + k_coh_search: the fused iteration's search + linearisation, two launches)
+#   k_tail      : the persistent settled-tail kernel, per ITERATION it runs: the same 48 (its per-point state never leaves LDS)
 KERNEL_BYTES_PER_POINT = {"k_match_g8": 32, "fused_pair": 48}
 ITER_BYTES_PER_POINT = 64    # P2Pl 48 B + 16 B (id, d2 written and re-read) for the split-kernel variant
 
@@ -151,6 +159,12 @@ def kernel_profile(capi, ds, local_rank):
         if pres.prof_launches[idx]:
             kern[name] = {"launches": int(pres.prof_launches[idx]), "total_ms": float(pres.prof_ms[idx]),
                           "avg_ms": float(pres.prof_ms[idx]) / int(pres.prof_launches[idx])}
+    if pres.prof_launches[3]:
+        # the persistent tail: ONE launch runs many iterations; avg_ms is per ITERATION (what a fused pair + update launch was)
+        its = max(int(pres.n_tail_iterations), 1)
+        kern["k_tail"] = {"launches": int(pres.prof_launches[3]), "total_ms": float(pres.prof_ms[3]), "iterations": its,
+                          "avg_ms": float(pres.prof_ms[3]) / its, "avg_ms_is": "per iteration (search + linearisation + exchange "
+                          "+ band select + solve + update of every settled iteration)"}
     if "k_coh_check" in kern:
         # the fused iteration's search + linearisation = the pair of launches (shortcut test + queued full searches)
         tot = kern["k_coh_check"]["total_ms"] + kern.get("k_coh_search", {"total_ms": 0.0})["total_ms"]
@@ -164,17 +178,118 @@ def pmc_traffic(workload, dom):
     """HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the number comes from the
     committed rocprofv3 --pmc passes of THIS command (tools/collect_profiles.sh; FETCH_SIZE doubled as the gfx950 guide
     prescribes and as the stream-kernel calibration in that file confirms)."""
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", name)))
             if pj.get("workload", "c2") != workload:
                 continue
             for kname, kv in pj["kernels"].items():
                 if kname.startswith(dom):
-                    return kv["hbm_bytes_per_launch_corrected"], f"profiles/{name} (2*FETCH_SIZE + WRITE_SIZE, bytes per launch)"
+                    return kv["hbm_bytes_per_launch_corrected"], (f"STATIC: read from the committed profiles/{name} (rocprofv3 --pmc passes of "
+                                                                  "this command, 2*FETCH_SIZE + WRITE_SIZE per launch), not measured in this run")
         except (OSError, KeyError, ValueError):
             pass
     return None, None
+
+
+def run_replicas(args, torch, capi, synth, dist, dev, rank, local_rank, world):
+    """BASELINE.json configs[4]: `--replicas` (64) independent C2-shaped registrations (seed + i), split over the ranks, 8 in
+    flight per GPU -- one handle, one HIP stream and one host thread each -- and no collective (replicas only; the
+    reference analogue is the per-submap-pair loop of PlaceRecognition.cpp:71-111).  One step = one pass over the whole batch."""
+    import gc
+    import threading
+    n_src, n_tgt, seed0 = WORKLOADS["c2"]
+    total = args.replicas
+    mine = list(range(rank, total, world))          # round-robin: equal shares whenever world divides the batch
+    S = min(args.streams, max(1, len(mine)))
+    T_init = np.eye(4, dtype=np.float32)
+    keep, regs = [], []
+    for i in mine:
+        sc = synth.make_scene(n_src, n_tgt, seed=seed0 + 100 + i)
+        dsi = DeviceScene(torch, dev, sc)
+        regs.append(dsi.make_reg(capi, chain_params(capi, local_rank)))
+        dsi.sc = None                                # host copies are not needed any more
+        keep.append(dsi)
+        del sc
+    groups = [list(range(k, len(regs), S)) for k in range(S)]
+    poses = [None] * len(regs)
+
+    def one_pass_all(n_pass):
+        go = threading.Barrier(S + 1)
+        errs = []
+
+        def work(idx):
+            try:
+                go.wait()
+                for _ in range(n_pass):
+                    for j in idx:
+                        poses[j] = regs[j].register(T_init)[0]
+            except Exception as e:   # noqa: BLE001
+                errs.append(repr(e))
+            finally:
+                go.wait()
+
+        ths = [threading.Thread(target=work, args=(g,)) for g in groups]
+        for th in ths:
+            th.start()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        go.wait()
+        t0 = time.perf_counter()
+        go.wait()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        for th in ths:
+            th.join()
+        if errs:
+            raise SystemExit("replica registration failed: " + errs[0])
+        return el
+
+    gc.collect()
+    gc.disable()
+    one_pass_all(max(1, args.warmup))
+    elapsed = one_pass_all(args.steps)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    # every timed pose against the same problem registered ALONE on this GPU (single stream, nothing else in flight)
+    timed = [np.array(p) for p in poses]
+    dmax = 0.0
+    for j, r in enumerate(regs):
+        Tj = r.register(T_init)[0]
+        dmax = max(dmax, float(np.abs(np.asarray(Tj) - timed[j]).max()))
+    ok = dmax <= 2e-6
+    # ... and a sample of them against the truth of its scene is implicit in tests/test_gpu_fullsize.py (oracle parity of C2)
+    if dist is not None:
+        t = torch.tensor([dmax], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dmax = float(t.item())
+        ok = dmax <= 2e-6
+    for r in regs:
+        r.close()
+    if rank == 0:
+        line = {
+            "metric": "ICP iterations/sec (batched submap registrations, one per HIP stream)",
+            "value": total * ITERS * args.steps / elapsed, "unit": "iter/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"c5: {total} independent registrations {n_src} -> {n_tgt} points (seed + i), {ITERS} iterations "
+                                   "each, icp.yaml chain as the headline; one step = one pass over the batch",
+                       "registrations": total, "registrations_per_gpu": len(mine), "streams_per_gpu": S,
+                       "n_source": n_src, "n_target": n_tgt, "iterations_per_registration": ITERS,
+                       "parallelism": f"replicas only: {total} registrations over {world} GPU(s), {S} handles / HIP streams / host "
+                                      "threads in flight per GPU, no collective"},
+            "poses_equal_single_stream": bool(ok), "max_abs_pose_diff_vs_single_stream": dmax,
+            "ms_per_registration_amortised": 1e3 * elapsed / (args.steps * max(len(mine), 1)),
+            "note": "total work (the 64-registration batch) is fixed as N grows: per-GPU efficiency = value(N) / (N * value(1))",
+        }
+        print(json.dumps(line), flush=True)
+    if not ok:
+        raise SystemExit(f"replicas: a timed pose differs from its single-stream registration by {dmax}")
 
 
 def main():
@@ -184,9 +299,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
                     help="default: c3 on one GPU, c4 (200k -> 20M, reading split over the ranks) on N > 1")
-    ap.add_argument("--mode", default="strong", choices=("strong", "weak"),
+    ap.add_argument("--mode", default="strong", choices=("strong", "weak", "replicas"),
                     help="N > 1 only.  strong (default, = BASELINE config C4): ONE reading split into N slices; "
-                         "weak: every rank holds a full-size slice of an N-times larger reading")
+                         "weak: every rank holds a full-size slice of an N-times larger reading; replicas (any N): BASELINE "
+                         "configs[4], 64 independent C2 registrations split over the ranks, 8 streams per GPU, no collectives")
+    ap.add_argument("--replicas", type=int, default=64, help="--mode replicas: registrations in the batch (all ranks together)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary objects (C2, C4 map, batched, GICP, R8x)")
     ap.add_argument("--streams", type=int, default=8,
@@ -220,6 +337,13 @@ def main():
                 dist.barrier()          # forms the communicator now (its banner goes to stderr)
             else:
                 dist.init_process_group(backend)
+
+    if args.mode == "replicas":
+        run_replicas(args, torch, capi, synth, dist, dev, rank, local_rank, world)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     force_dist = os.environ.get("O3D_BENCH_FORCE_DIST") == "1"   # rehearsal: N>1 code path with one rank
     multi = world > 1 or force_dist
@@ -401,16 +525,17 @@ def main():
                     regs.append(r)
                 per = max(2, args.steps // 2)
                 rates = []
+                lastT = [None] * args.streams
                 for _rep in range(3):       # the aggregate depends on how the streams land on the hardware queues: 3 runs
                     go = threading.Barrier(args.streams + 1)
 
-                    def work(r):
+                    def work(r, i):
                         go.wait()
                         for _ in range(per):
-                            r.register(T_init)      # ctypes releases the GIL: the host threads really run in parallel
+                            lastT[i] = r.register(T_init)[0]   # ctypes releases the GIL: the host threads really run in parallel
                         go.wait()
 
-                    ths = [threading.Thread(target=work, args=(r,)) for r in regs]
+                    ths = [threading.Thread(target=work, args=(r, i)) for i, r in enumerate(regs)]
                     for th in ths:
                         th.start()
                     torch.cuda.synchronize()
@@ -422,9 +547,15 @@ def main():
                         th.join()
                     rates.append(args.streams * per * ITERS / tb)
                 rates.sort()
+                # every stream's pose against the single-stream registration of the same clouds (T2): one of the streams at a time
+                # runs its tail in the persistent kernel, the others on the three-launch iteration -- same ids, sums equal up to
+                # the fp64 summation order
+                dmax = max(float(np.abs(np.asarray(Ti) - np.asarray(T2)).max()) for Ti in lastT)
+                assert dmax <= 2e-6, f"batched registrations disagree with the single-stream pose by {dmax}"
                 extras["batched"] = {"streams": args.streams, "registrations": args.streams * per, "workload": "c2",
                                      "iter_per_s": rates[1], "iter_per_s_min_max_of_3": [rates[0], rates[2]],
-                                     "ms_per_registration_amortised": 1e3 * ITERS / rates[1]}
+                                     "ms_per_registration_amortised": 1e3 * ITERS / rates[1],
+                                     "max_abs_pose_diff_vs_single_stream": dmax}
                 for r in regs:
                     r.close()
             # (4) the GICP cost (the north star's cost function; SURVEY 8d: 72 B/pt + 16 B/pt for the split kernels) on
@@ -479,7 +610,7 @@ def main():
             scaling = "weak"
         else:
             value = ITERS * args.steps / elapsed              # whole-reading iterations
-            scaling = "strong" if multi else "weak"           # N = 1: per-GPU work is the whole job either way
+            scaling = "strong" if multi else None             # N = 1: the label means nothing
         line = {
             "metric": "ICP iterations/sec (scan-to-map)",
             "value": value, "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -495,12 +626,21 @@ def main():
                        "use_xicp": 0, "cell_size_m": info.cell_size, "n_bricks": info.n_bricks,
                        "table_MB": info.table_bytes / 1e6},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": achieved / HBM_PEAK_GBS, "peak_measured": HBM_MEASURED_GBS,
+                         "frac_of_measured_peak": achieved / HBM_MEASURED_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": n_local * bytes_pp,
                          "kernel_ms": kern[dom]["avg_ms"], "launches": kern[dom]["launches"],
                          "bytes_per_point": bytes_pp,
                          "limiter": "latency of dependent round trips, then Infinity-Cache/HBM fetches of the candidate "
                                     "records an exact search has to look at (DESIGN.md section 6, profiles/)"},
+            "roofline_tail": (None if multi or "k_tail" not in kern else {
+                "bound": "hbm", "kernel": "k_tail (persistent settled tail), per iteration",
+                "achieved": n_local * 48 / (kern["k_tail"]["avg_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": n_local * 48 / (kern["k_tail"]["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "traffic": pmc_traffic(workload, "k_tail")[0], "algorithmic_bytes_per_iteration": n_local * 48,
+                "iteration_ms": kern["k_tail"]["avg_ms"], "iterations": kern["k_tail"]["iterations"],
+                "launches": kern["k_tail"]["launches"],
+                "note": "replaces k_coh_check + k_coh_search + k_reduce_update of every settled iteration (round 2: roofline_fused)"}),
             "roofline_fused": (None if multi or "fused_pair" not in kern else {
                 "bound": "hbm", "kernel": "k_coh_check + k_coh_search (settled iterations: search + linearisation)",
                 "achieved": n_local * 48 / (kern["fused_pair"]["avg_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -513,6 +653,7 @@ def main():
             "target_build_ms": float(res_final.target_build_ms) if not multi else None,
             "source_prep_ms": float(res_final.source_prep_ms) if not multi else None,
             "band_stalls_last_step": int(res_final.n_band_stalls) if not multi else None,
+            "tail_iterations_last_step": int(res_final.n_tail_iterations) if not multi else None,
         }
         line.update(extras)
         if single is not None:
@@ -544,6 +685,7 @@ def main():
             line["pose_vs_truth"] = {"trans_m": et, "rot_rad": er}
         print(json.dumps(line), flush=True)
     if dist is not None:
+        dist.barrier()      # rank 0 was still timing its single-GPU denominator: nobody tears the group down before it is done
         dist.destroy_process_group()
 
 

@@ -80,7 +80,7 @@ typedef struct {
     float   min_diff_trans;
     int32_t smooth_len;
     int32_t fixed_iters;        /* >0: run exactly this many iterations, checkers ignored (throughput runs) */
-    /* GICP termination (Gauss-Newton, rotation-first tangent) */
+    /* GICP termination, rule 0 (Gauss-Newton, rotation-first tangent); rule 1: gicp_stop_rule below */
     float   gicp_rot_eps;       /* rad */
     float   gicp_trans_eps;     /* m */
     /* device-side search structure */
@@ -97,7 +97,18 @@ typedef struct {
     float   xicp_insufficient;  /* insufficientInformationThreshold (180 shipped): sum over alignment > cos(strong angle) */
     float   xicp_min_angle_deg; /* point2NormalMinimalAlignmentAngleThreshold (80 shipped) */
     float   xicp_strong_angle_deg; /* point2NormalStrongAlignmentAngleThreshold (45 shipped) */
-    int32_t reserved[2];
+    /* GICP stop rule.  0: |d_rot| < gicp_rot_eps && |d_trans| < gicp_trans_eps after an update (small_gicp's
+       TerminationCriteria), or max_iter updates.  1: open3d::pipelines::registration::ICPConvergenceCriteria as
+       RegistrationIcpGeneralized uses it (open3d_slam/src/CloudRegistration.cpp:16-21,45-52: only max_iteration_ is
+       configured, relative_fitness_ = relative_rmse_ = 1e-6 by default): after every update the correspondences are
+       re-evaluated at the new pose and the loop stops when |fitness - previous fitness| < gicp_rel_fitness AND
+       |inlier_rmse - previous inlier_rmse| < gicp_rel_rmse (fitness = matched / N, inlier_rmse = sqrt(sum d2 / matched)),
+       else after max_iter updates (+ the final evaluation, whose fitness / rmse are reported).  Open3D 0.15.1 is an
+       un-vendored dependency: restated from its published RegistrationICP loop, PARITY UNPINNED. */
+    int32_t gicp_stop_rule;
+    float   gicp_rel_fitness;   /* relative_fitness_ (1e-6) */
+    float   gicp_rel_rmse;      /* relative_rmse_ (1e-6) */
+    int32_t reserved;
 } reg_params;
 
 typedef struct {

@@ -40,7 +40,8 @@ class RegParams(C.Structure):
                 ("fixed_iters", C.c_int32), ("gicp_rot_eps", C.c_float), ("gicp_trans_eps", C.c_float),
                 ("cell_size", C.c_float), ("device", C.c_int32), ("sort_source", C.c_int32), ("use_xicp", C.c_int32),
                 ("xicp_enough", C.c_float), ("xicp_insufficient", C.c_float), ("xicp_min_angle_deg", C.c_float),
-                ("xicp_strong_angle_deg", C.c_float), ("reserved", C.c_int32 * 2)]
+                ("xicp_strong_angle_deg", C.c_float), ("gicp_stop_rule", C.c_int32), ("gicp_rel_fitness", C.c_float),
+                ("gicp_rel_rmse", C.c_float), ("reserved", C.c_int32)]
     profile_loop = match_variant = debug_flags = disable_halo = lanes_per_point = disable_fused = 0
 
 

@@ -1,6 +1,38 @@
 // host_dist.hpp -- multi-GPU entry points (host-synchronous halves, stream-ordered phases), measurement hook, host-only exports
 // Part of the single translation unit reg_core.hip (included there, in this order; not a standalone header).
 #pragma once
+#include <thread>
+
+// Deadline for every wait of the distributed loop: a peer that died, or a collective that never completes, keeps the
+// stream busy without raising a fault -- the survivors must not spin forever.
+struct Deadline {
+    std::chrono::steady_clock::time_point t_end;
+    explicit Deadline(double seconds) : t_end(std::chrono::steady_clock::now() + std::chrono::duration_cast<std::chrono::steady_clock::duration>(std::chrono::duration<double>(seconds))) {}
+    bool expired() const { return std::chrono::steady_clock::now() > t_end; }
+};
+
+// hipStreamSynchronize with a deadline: a collective whose peer died never completes and raises no fault.
+static reg_status dist_stream_wait(reg_handle* h, double timeout_s, const char* what) {
+    const Deadline dl(timeout_s);
+    for (unsigned spins = 0;; ++spins) {
+        const hipError_t e = hipStreamQuery(h->stream);
+        if (e == hipSuccess) return REG_OK;
+        if (e != hipErrorNotReady) {
+            h->err = std::string(what) + ": " + hipGetErrorString(e);
+            return REG_DEVICE_ERROR;
+        }
+        if ((spins & 63) == 63) {
+            if (dl.expired()) {
+                h->err = std::string(what) + ": the stream did not drain within the deadline (O3D_DIST_TIMEOUT_S): a peer died or a "
+                                              "collective never completed";
+                return REG_DEVICE_ERROR;
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        } else {
+            __builtin_ia32_pause();
+        }
+    }
+}
 
 extern "C" {
 
@@ -444,7 +476,13 @@ reg_status reg_dist_finish(reg_handle* h, float T_out[16], reg_result* res) {
     reg_result local;
     if (!res) res = &local;
     std::memset(res, 0, sizeof(*res));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    // (with a deadline when the stream carries collectives: a dead peer must not hang the survivors here either)
+    if (h->dist) {
+        s = dist_stream_wait(h, h->env.dist_timeout_s, "reg_dist_finish");
+        if (s != REG_OK) return s;
+    } else {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
     HIPCHK(h, hipGetLastError());
     const HostMirror* mir = h->h_mirror;
     if (mirror_seq(h) <= h->dist_seq0) {

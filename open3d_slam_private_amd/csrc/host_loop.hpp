@@ -125,6 +125,10 @@ static reg_status build_iter_state(reg_handle* h, const float* T_row, int update
     st->update = update;
     st->gicp_rot_eps = h->prm.gicp_rot_eps;
     st->gicp_trans_eps = h->prm.gicp_trans_eps;
+    st->gicp_stop_rule = h->prm.gicp_stop_rule;
+    st->gicp_rel_fitness = h->prm.gicp_rel_fitness;
+    st->gicp_rel_rmse = h->prm.gicp_rel_rmse;
+    st->n_total = (float)(h->n_total_hint > 0 ? h->n_total_hint : h->n);
     st->band_lo = st->band_hi = INFINITY;
     st->limit_last = st->limit_prev = INFINITY;
     st->use_trim = (h->prm.cost == REG_COST_P2PL && h->prm.use_trimmed) ? 1 : 0;
@@ -604,7 +608,8 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
     rmark("ev0");
     const unsigned long long seq0 = h->seq;
     const int fixed = h->prm.fixed_iters;
-    const int limit = fixed > 0 ? fixed : h->prm.max_iter;
+    // (GICP stop rule 1 re-evaluates the correspondences once more after the last update: one more sequence)
+    const int limit = fixed > 0 ? fixed : h->prm.max_iter + ((!p2pl && h->prm.gicp_stop_rule == 1) ? 1 : 0);
     // Iterations 0..kGenericFirst-1 run on the generic (select-based) path: the trimmed limit still moves too
     // much to be predicted.  Afterwards the fused two-kernel iteration is used; if its band prediction fails the
     // device stalls the queue and the host repairs that iteration on the generic path.

@@ -10,6 +10,7 @@
 #pragma once
 
 #include <dlfcn.h>
+#include <thread>
 #include <rccl/rccl.h>   // types and signatures; the functions themselves are resolved with dlopen at reg_dist_init
 
 // =================================================================================================
@@ -167,8 +168,18 @@ struct RcclApi {
         AllReduce = (decltype(AllReduce))sym("ncclAllReduce");
         AllGather = (decltype(AllGather))sym("ncclAllGather");
         GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
-        if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce || !AllGather) {
+        auto GetVersion = (ncclResult_t (*)(int*))sym("ncclGetVersion");
+        if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce || !AllGather || !GetVersion) {
             err = "librccl lacks an expected entry point";
+            lib = nullptr;
+            return false;
+        }
+        // The API is compiled against <rccl/rccl.h> but resolved from whatever librccl the process carries (PyTorch bundles
+        // its own): ncclUniqueId, the enums and the call signatures are only guaranteed within one major version.
+        int ver = 0;
+        if (GetVersion(&ver) != ncclSuccess || ver / 10000 != NCCL_MAJOR) {
+            err = "librccl in this process reports version " + std::to_string(ver) + ", the library was built against major " +
+                  std::to_string((int)NCCL_MAJOR);
             lib = nullptr;
             return false;
         }
@@ -226,14 +237,6 @@ static reg_status dist_all_gather(reg_handle* h, const void* send, void* recv, i
         return dist_fail(h, "custom all_gather failed");
     return REG_OK;
 }
-
-// Deadline for every wait of the distributed loop: a peer that died, or a collective that never completes, keeps the
-// stream busy without raising a fault -- the survivors must not spin forever.
-struct Deadline {
-    std::chrono::steady_clock::time_point t_end;
-    explicit Deadline(double seconds) : t_end(std::chrono::steady_clock::now() + std::chrono::duration_cast<std::chrono::steady_clock::duration>(std::chrono::duration<double>(seconds))) {}
-    bool expired() const { return std::chrono::steady_clock::now() > t_end; }
-};
 
 // Blocks until sequence `seq_rel` has reported (reply.available = 1) or can no longer report because the stream drained
 // without it (available = 0).
@@ -301,7 +304,8 @@ static reg_status dist_refresh_counts(reg_handle* h) {
     reg_status s = dist_all_gather(h, dev + d->n_ranks, dev, 8);
     if (s != REG_OK) return s;
     HIPCHK(h, hipMemcpyAsync(d->h_count, dev, (size_t)d->n_ranks * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    s = dist_stream_wait(h, d->timeout_s, "slice sizes of the reading (all-gather)");
+    if (s != REG_OK) return s;
     d->n_global = 0;
     d->n_max = 0;
     for (int r = 0; r < d->n_ranks; ++r) {
@@ -310,6 +314,7 @@ static reg_status dist_refresh_counts(reg_handle* h) {
         d->n_max = std::max<int64_t>(d->n_max, d->h_count[r]);
     }
     d->src_epoch_seen = h->src_epoch;
+    h->n_total_hint = d->n_global;
     void *a = nullptr, *b = nullptr;
     int64_t nbytes = 0;
     if (h->prm.cost == REG_COST_P2PL) {
@@ -366,7 +371,7 @@ static reg_status dist_init_common(reg_handle* h, int rank, int n_ranks, DistCtx
     d->n_ranks = n_ranks;
     d->rank = rank;
     std::memset(&d->custom, 0, sizeof(d->custom));
-    if (const char* v = getenv("O3D_DIST_TIMEOUT_S")) d->timeout_s = std::max(0.5, atof(v));
+    d->timeout_s = h->env.dist_timeout_s;
     if (const char* v = getenv("O3D_DIST_SETTLE")) d->settle_tol = (float)atof(v);
     if (hipHostMalloc((void**)&d->h_count, (size_t)(n_ranks + 1) * 8, hipHostMallocDefault) != hipSuccess) {
         delete d;
@@ -413,8 +418,10 @@ reg_status reg_dist_shutdown(reg_handle* h) {
     if (!h) return REG_BAD_ARGUMENT;
     DistCtx* d = h->dist;
     if (!d) return REG_OK;
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
-    if (d->use_rccl && d->comm) (void)g_rccl.CommDestroy(d->comm);
+    // (a deadline here too: collectives still enqueued behind a dead peer never complete; the communicator is then abandoned
+    //  rather than destroyed -- ncclCommDestroy would wait for them)
+    const bool drained = !h->stream || dist_stream_wait(h, d->timeout_s, "reg_dist_shutdown") == REG_OK;
+    if (d->use_rccl && d->comm && drained) (void)g_rccl.CommDestroy(d->comm);
     d->counts.release();
     if (d->h_count) (void)hipHostFree(d->h_count);
     delete d;

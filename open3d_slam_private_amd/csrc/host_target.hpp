@@ -43,6 +43,7 @@ struct EnvSwitches {
     bool coh_stats = false;     // O3D_COH_STATS: share of the reading points the coherent fused kernel had to search
     bool no_tail = false;       // O3D_NO_TAIL: three-launch fused iterations instead of the persistent tail kernel (A/B, escape hatch)
     int tail_wpc = 0;           // O3D_TAIL_WPC: cap on the tail kernel's workgroups per XCD class (0: CUs / 8)
+    double dist_timeout_s = 30.0; // O3D_DIST_TIMEOUT_S: deadline of every wait of the distributed path
     float tail_timeout_s = 2.f; // O3D_TAIL_TIMEOUT_S: bound of every grid barrier of the tail kernel
     float tail_settle_tol = 1.2f; // O3D_TAIL_SETTLE: relative change of the trimmed limit below which the tail kernel takes over
     int lookahead = 2;          // O3D_KAHEAD
@@ -66,6 +67,7 @@ struct EnvSwitches {
         coh_stats = getenv("O3D_COH_STATS") != nullptr;
         no_tail = getenv("O3D_NO_TAIL") != nullptr;
         if (const char* v = getenv("O3D_TAIL_WPC")) tail_wpc = std::max(0, atoi(v));
+        if (const char* v = getenv("O3D_DIST_TIMEOUT_S")) dist_timeout_s = std::max(0.5, atof(v));
         if (const char* v = getenv("O3D_TAIL_SETTLE")) tail_settle_tol = (float)atof(v);
         if (const char* v = getenv("O3D_TAIL_TIMEOUT_S")) tail_timeout_s = std::min(30.f, std::max(0.01f, (float)atof(v)));
         if (const char* v = getenv("O3D_KAHEAD")) lookahead = std::max(1, atoi(v));
@@ -141,6 +143,7 @@ struct reg_handle {
     DevBuf i_hint, s_keys, s_keys2, s_perm, s_perm2, s_tmp, i_tmpf;
     const uint32_t* perm = nullptr;   // slot -> input index (null: identity)
     int last_stalls = 0;
+    int64_t n_total_hint = 0;   // multi-GPU: points of the WHOLE reading (fitness of the GICP stop rule); 0: this handle's n
     int last_tail_launches = 0, last_tail_iters = 0;   // persistent tail: launches / iterations of the last reg_register
     DevBuf i_tail_sync, i_tail_rows, i_tail_band;      // persistent tail: counters | per-workgroup sum rows | band records
     unsigned long long dist_seq0 = 0;
@@ -201,6 +204,9 @@ void reg_default_params(reg_params* p) {
     p->xicp_insufficient = 180.f;
     p->xicp_min_angle_deg = 80.f;
     p->xicp_strong_angle_deg = 45.f;
+    p->gicp_stop_rule = 0;
+    p->gicp_rel_fitness = 1e-6f;        // open3d ICPConvergenceCriteria defaults
+    p->gicp_rel_rmse = 1e-6f;
 }
 
 void reg_shipped_params(reg_params* p) {
@@ -228,6 +234,7 @@ reg_status reg_create(const reg_params* p, reg_handle** out) {
     if (p->use_trimmed && !(p->trim_ratio >= 0.f && p->trim_ratio <= 1.f)) return REG_BAD_ARGUMENT;
     if (p->fixed_iters <= 0 && p->max_iter <= 0) return REG_BAD_ARGUMENT;
     if (p->use_xicp && p->cost != REG_COST_P2PL) return REG_BAD_ARGUMENT;   // the analysis expects point-to-plane (ICP.cpp:1118)
+    if (p->gicp_stop_rule != 0 && p->gicp_stop_rule != 1) return REG_BAD_ARGUMENT;
     reg_handle* h = new reg_handle();
     h->prm = *p;
     std::memset(&h->dbg, 0, sizeof(h->dbg));
@@ -1108,9 +1115,9 @@ reg_status reg_smooth_normals(reg_handle* h, float* normals, const int32_t* ids,
     unsigned int* n_done = reinterpret_cast<unsigned int*>(level + n);
     HIPCHK(h, hipMemcpyAsync(orig, d_n, (size_t)n * 12, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(h, hipMemsetAsync(level, 0xff, (size_t)n * 4, h->stream));
-    HIPCHK(h, hipMemsetAsync(n_done, 0, 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(n_done, 0, 8, h->stream));   // [0] finished points, [1] an id >= n was seen
     int pass = 0;
-    unsigned int done = 0;
+    unsigned int done = 0, done2[2] = {0, 0};
     const int batch = 32;   // passes between two looks at the count (finished sweeps are cheap no-ops)
     while (done < (unsigned int)n) {
         if ((int64_t)pass > n) {
@@ -1119,8 +1126,13 @@ reg_status reg_smooth_normals(reg_handle* h, float* normals, const int32_t* ids,
         }
         for (int b = 0; b < batch; ++b, ++pass)
             k_smooth_pass<<<grid_for(n), 256, 0, h->stream>>>(orig, d_n, d_i, n, k, pass, level, n_done);
-        HIPCHK(h, hipMemcpyAsync(&done, n_done, 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(done2, n_done, 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
+        done = done2[0];
+        if (done2[1]) {
+            h->err = "reg_smooth_normals: a neighbour id is >= n";
+            return REG_BAD_ARGUMENT;
+        }
     }
     if (n_passes) *n_passes = pass;
     if (!on_device) {
@@ -1273,6 +1285,7 @@ reg_status reg_set_source(reg_handle* h, const float* xyz, int64_t xyz_stride, c
         if (s != REG_OK) return s;
     }
     h->n = n;
+    h->n_total_hint = 0;
     ++h->src_epoch;
     h->has_snrm = nrm != nullptr;
     h->has_scov = cov != nullptr;

@@ -349,6 +349,10 @@ k_smooth_pass(const float* __restrict__ orig, float* cur, const int32_t* __restr
     const int32_t* row = ids + (size_t)i * k;
     for (int j = 0; j < k; ++j) {
         const int32_t r = row[j];
+        if ((int64_t)r >= n) {   // an id beyond the cloud: reported (n_done[1]), never dereferenced
+            n_done[1] = 1u;
+            return;
+        }
         if (r >= 0 && r < i) {
             const int lv = level[r];
             if (lv < 0 || lv >= pass) return;   // not finished before this pass started

@@ -35,7 +35,10 @@
 #define O3D_TAIL_ACQ 0   // 1: agent-scope acquire fence after the poll in addition to the sc1 loads (+1.5 us per exchange, measured;
                          // the hand-off form below needs none: every handed-off byte is loaded sc1)
 #endif
-constexpr int kTailThreads = 512;       // 8 waves = 2 per SIMD: 256 VGPRs per lane (a 1024-thread workgroup, capped at 128, spilled ~90
+#ifndef O3D_TAIL_THREADS
+#define O3D_TAIL_THREADS 512
+#endif
+constexpr int kTailThreads = O3D_TAIL_THREADS;   // 8 waves = 2 per SIMD: 256 VGPRs per lane (a 1024-thread workgroup, capped at 128, spilled ~90
                                         // registers around the search and paid a scratch round trip in every phase)
 constexpr int kTailSlots = 1024;        // reading-point slots per workgroup: thread t owns slots t and t + 512
 constexpr int kTailPts = kTailSlots / kTailThreads;
@@ -820,10 +823,12 @@ k_tail(const float4* __restrict__ src, const float4* __restrict__ src_nrm, IterS
                 __syncthreads();
                 TAIL_STAMP(7);   // band: staging
                 {
-                    // exclusive scan of the kTailBins counts, two adjacent bins per thread
-                    const uint32_t h0 = hist[2 * t], h1 = hist[2 * t + 1];
-                    hist[2 * t] = 0u;   // ready for the next iteration
-                    hist[2 * t + 1] = 0u;
+                    // exclusive scan of the kTailBins counts, kBpt adjacent bins per thread
+                    constexpr int kBpt = kTailBins / kTailThreads;
+                    static_assert(kBpt == 1 || kBpt == 2, "one or two bins per thread");
+                    const uint32_t h0 = hist[kBpt * t], h1 = kBpt == 2 ? hist[kBpt * t + kBpt - 1] : 0u;
+                    hist[kBpt * t] = 0u;   // ready for the next iteration
+                    if (kBpt == 2) hist[kBpt * t + 1] = 0u;
                     const uint32_t loc = h0 + h1;
                     uint32_t incl = loc;
 #pragma unroll
@@ -839,7 +844,7 @@ k_tail(const float4* __restrict__ src, const float4* __restrict__ src_nrm, IterS
                     const uint32_t excl = base + incl - loc, rank = kq - n_below;
                     if (loc && rank >= excl && rank < excl + loc) {   // exactly one thread
                         const bool first = rank < excl + h0;
-                        misc[6] = (uint32_t)(2 * t + (first ? 0 : 1));
+                        misc[6] = (uint32_t)(kBpt * t + (first ? 0 : 1));
                         misc[7] = first ? rank - excl : rank - excl - h0;
                         misc[8] = first ? h0 : h1;
                     }

@@ -166,6 +166,7 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
                 off += min(cnt, (uint32_t)contrib_cap);
             }
             rk_off[n_ranks] = off;
+            if (off > (uint32_t)kBandCap) bad = 1;   // more records than the LDS staging holds (large groups): stall + generic repair
             rk_bad = bad;
         }
         __syncthreads();
@@ -565,9 +566,26 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
                 else
                     iterate = sit->chk.check(Tn);
                 if (!iterate) sit->done = 1;
+            } else if (sit->gicp_stop_rule == 1 && sit->fixed_iters <= 0 &&
+                       ((sit->iterations >= 1 &&
+                         fabs(r_tot28 / (double)sit->n_total - sit->fit_prev) < (double)sit->gicp_rel_fitness &&
+                         fabs(sqrt(tot[30] / r_tot28) - sit->rmse_prev) < (double)sit->gicp_rel_rmse) ||
+                        sit->iterations >= sit->max_iter)) {
+                // Open3D ICPConvergenceCriteria: this evaluation's fitness / rmse against the previous one's; no further update.
+                // The sums reported with this sequence belong to the final pose (T_prev == T).
+                if (sit->iterations >= sit->max_iter &&
+                    !(sit->iterations >= 1 && fabs(r_tot28 / (double)sit->n_total - sit->fit_prev) < (double)sit->gicp_rel_fitness &&
+                      fabs(sqrt(tot[30] / r_tot28) - sit->rmse_prev) < (double)sit->gicp_rel_rmse))
+                    sit->chk.max_iter_reached = true;
+                else
+                    sit->chk.converged = true;
+                for (int i = 0; i < 16; ++i) sit->T_prev[i] = r_T[i];
+                sit->done = 1;
             } else {
                 double dl[6], E[16], Tn[16];
                 int rank = 6;
+                sit->fit_prev = r_tot28 / (double)sit->n_total;
+                sit->rmse_prev = sqrt(tot[30] / r_tot28);
                 if (well) {
                     for (int i = 0; i < 6; ++i) dl[i] = xsol[i];
                 } else {
@@ -590,6 +608,8 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
                 sit->iterations += 1;
                 if (sit->fixed_iters > 0) {
                     if (sit->iterations >= sit->fixed_iters) sit->done = 1;
+                } else if (sit->gicp_stop_rule == 1) {
+                    // decided by the next evaluation (above)
                 } else {
                     const double dr = sqrt(dl[0] * dl[0] + dl[1] * dl[1] + dl[2] * dl[2]);
                     const double dt = sqrt(dl[3] * dl[3] + dl[4] * dl[4] + dl[5] * dl[5]);

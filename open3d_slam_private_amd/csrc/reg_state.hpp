@@ -19,6 +19,10 @@ struct IterState {
     int max_iter;
     int update;           // 0: reduce only (reg_linearize / distributed halves), 1: solve + update + check
     float gicp_rot_eps, gicp_trans_eps;
+    int gicp_stop_rule;       // 1: Open3D ICPConvergenceCriteria (relative fitness / rmse between consecutive evaluations)
+    float gicp_rel_fitness, gicp_rel_rmse;
+    float n_total;            // reading points (all ranks): fitness = matched / n_total
+    double fit_prev, rmse_prev;
     double sums[kSums];
     // fused path (k_iter_fused): predicted band [band_lo, band_hi) around the trimmed-quantile limit
     float band_lo, band_hi;   // +inf / +inf: no trimming (every finite match is inside)

@@ -265,6 +265,8 @@ class RegistrationIcpGeneralized:
     def __init__(self, maxCorrespondenceDistance_=1.0, max_iteration_=30):
         self.maxCorrespondenceDistance_ = maxCorrespondenceDistance_
         self.max_iteration_ = max_iteration_
+        self.relative_fitness_ = 1e-6   # open3d::pipelines::registration::ICPConvergenceCriteria defaults
+        self.relative_rmse_ = 1e-6
         self._reg = None
 
     def registerClouds(self, source: DataPoints, target: DataPoints, init=None) -> RegistrationResult:
@@ -273,6 +275,11 @@ class RegistrationIcpGeneralized:
         p.use_trimmed = 0
         p.max_dist = self.maxCorrespondenceDistance_
         p.max_iter = self.max_iteration_
+        # icpConvergenceCriteria_: only max_iteration_ is configured (CloudRegistration.cpp:45-52), so Open3D's defaults
+        # relative_fitness_ = relative_rmse_ = 1e-6 end the loop
+        p.gicp_stop_rule = 1
+        p.gicp_rel_fitness = self.relative_fitness_
+        p.gicp_rel_rmse = self.relative_rmse_
         reg = capi.Registration(p)
         try:
             reg.set_target(target.features, None, target.covariances)

@@ -1309,10 +1309,27 @@ static void se3_exp(const double d[6], double T[16]) {
 
 /* Gauss-Newton GICP registration (fp32 transform for matching, fp64 algebra).  Termination:
    |d_rot| < rot_eps && |d_trans| < trans_eps, or max_iter (fixed_iters>0: exactly that many). */
+ORC_API int orc_icp_gicp2(const float* tgt_xyz, int64_t tgt_stride, const float* tgt_cov, int64_t m,
+                          const float* src_xyz, int64_t src_stride, const float* src_cov, int64_t n,
+                          const float T_init[16], float max_dist, int max_iter, int fixed_iters, double rot_eps,
+                          double trans_eps, int stop_rule, double rel_fitness, double rel_rmse, int n_threads,
+                          float T_out[16], orc_result* res);
 ORC_API int orc_icp_gicp(const float* tgt_xyz, int64_t tgt_stride, const float* tgt_cov, int64_t m,
                          const float* src_xyz, int64_t src_stride, const float* src_cov, int64_t n,
                          const float T_init[16], float max_dist, int max_iter, int fixed_iters, double rot_eps,
                          double trans_eps, int n_threads, float T_out[16], orc_result* res) {
+    return orc_icp_gicp2(tgt_xyz, tgt_stride, tgt_cov, m, src_xyz, src_stride, src_cov, n, T_init, max_dist, max_iter,
+                         fixed_iters, rot_eps, trans_eps, 0, 0.0, 0.0, n_threads, T_out, res);
+}
+/* stop_rule 1: Open3D 0.15.1 ICPConvergenceCriteria as open3d_slam's RegistrationIcpGeneralized uses it
+   (open3d_slam/src/CloudRegistration.cpp:16-21,45-52; arithmetic in the un-vendored Open3D: restated from its published
+   RegistrationICP loop): evaluate the correspondences, update, evaluate again; stop when |fitness - previous| < rel_fitness
+   and |inlier_rmse - previous| < rel_rmse, else after max_iter updates (the last evaluation is the reported one). */
+ORC_API int orc_icp_gicp2(const float* tgt_xyz, int64_t tgt_stride, const float* tgt_cov, int64_t m,
+                          const float* src_xyz, int64_t src_stride, const float* src_cov, int64_t n,
+                          const float T_init[16], float max_dist, int max_iter, int fixed_iters, double rot_eps,
+                          double trans_eps, int stop_rule, double rel_fitness, double rel_rmse, int n_threads,
+                          float T_out[16], orc_result* res) {
     memset(res, 0, sizeof(*res));
     memcpy(T_out, T_init, 64);
     if (m == 0) return res->status = 1;
@@ -1323,8 +1340,10 @@ ORC_API int orc_icp_gicp(const float* tgt_xyz, int64_t tgt_stride, const float* 
     double Td[16];
     for (int i = 0; i < 16; ++i) Td[i] = T_init[i];
     float Tf[16];
-    int its = fixed_iters > 0 ? fixed_iters : max_iter;
+    const int rule1 = stop_rule == 1 && fixed_iters <= 0;
+    int its = fixed_iters > 0 ? fixed_iters : max_iter + (rule1 ? 1 : 0);
     int status = 0;
+    double fit_prev = 0, rmse_prev = 0;
     const double t_loop0 = now_s();
     for (int it = 0; it < its; ++it) {
         for (int i = 0; i < 16; ++i) Tf[i] = (float)Td[i];
@@ -1337,6 +1356,24 @@ ORC_API int orc_icp_gicp(const float* tgt_xyz, int64_t tgt_stride, const float* 
         if (cnt == 0) {
             status = 3;
             break;
+        }
+        if (rule1) {
+            double sd2 = 0;
+            for (int64_t i = 0; i < n; ++i)
+                if (ids[i] >= 0) sd2 += (double)d2[i];
+            const double fit = (double)cnt / (double)(float)n, rmse = sqrt(sd2 / (double)cnt);
+            const int conv = it >= 1 && fabs(fit - fit_prev) < rel_fitness && fabs(rmse - rmse_prev) < rel_rmse;
+            if (conv || it >= max_iter) {
+                if (conv)
+                    res->converged = 1;
+                else
+                    res->max_iter_reached = 1;
+                for (int i = 0; i < 36; ++i) res->A_last[i] = (float)H[i];
+                for (int i = 0; i < 6; ++i) res->b_last[i] = (float)b[i];
+                break;
+            }
+            fit_prev = fit;
+            rmse_prev = rmse;
         }
         /* delta = solve(H, -b) via eigen-decomposition (H is SPD) */
         double M[36], V[36], lam[6], dl[6] = {0, 0, 0, 0, 0, 0};
@@ -1364,7 +1401,7 @@ ORC_API int orc_icp_gicp(const float* tgt_xyz, int64_t tgt_stride, const float* 
         res->iterations = it + 1;
         for (int i = 0; i < 36; ++i) res->A_last[i] = (float)H[i];
         for (int i = 0; i < 6; ++i) res->b_last[i] = (float)b[i];
-        if (fixed_iters <= 0) {
+        if (fixed_iters <= 0 && !rule1) {
             double dr = sqrt(dl[0] * dl[0] + dl[1] * dl[1] + dl[2] * dl[2]);
             double dt = sqrt(dl[3] * dl[3] + dl[4] * dl[4] + dl[5] * dl[5]);
             if (dr < rot_eps && dt < trans_eps) {
@@ -1374,7 +1411,7 @@ ORC_API int orc_icp_gicp(const float* tgt_xyz, int64_t tgt_stride, const float* 
         }
     }
     res->loop_seconds = now_s() - t_loop0;
-    if (!res->converged && fixed_iters <= 0 && res->iterations >= max_iter) res->max_iter_reached = 1;
+    if (!rule1 && !res->converged && fixed_iters <= 0 && res->iterations >= max_iter) res->max_iter_reached = 1;
     res->status = status;
     for (int i = 0; i < 16; ++i) T_out[i] = (float)Td[i];
     memcpy(res->T_iter, T_out, 64);

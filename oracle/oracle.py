@@ -230,16 +230,18 @@ def gicp_normal_eq(src_xyz, src_cov, tgt_xyz, tgt_cov, T, ids):
 
 
 def icp_gicp(tgt_xyz, tgt_cov, src_xyz, src_cov, T_init=None, *, max_dist=math.inf, max_iter=20, fixed_iters=0,
-             rot_eps=0.1 * math.pi / 180.0, trans_eps=1e-3, n_threads=1):
+             rot_eps=0.1 * math.pi / 180.0, trans_eps=1e-3, n_threads=1, stop_rule=0, rel_fitness=1e-6, rel_rmse=1e-6):
+    """stop_rule 1: Open3D ICPConvergenceCriteria semantics (CloudRegistration.cpp:16-21,45-52), see orc_icp_gicp2."""
     tgt, src = _f32(tgt_xyz), _f32(src_xyz)
     tc, sc = _f32(tgt_cov, 6), _f32(src_cov, 6)
     T0 = _f32(np.eye(4) if T_init is None else T_init).reshape(16)
     T = np.zeros(16, np.float32)
     res = Result()
-    lib().orc_icp_gicp(_p(tgt), C.c_int64(tgt.shape[1]), _p(tc), C.c_int64(tgt.shape[0]), _p(src),
-                       C.c_int64(src.shape[1]), _p(sc), C.c_int64(src.shape[0]), _p(T0), C.c_float(max_dist),
-                       C.c_int(max_iter), C.c_int(fixed_iters), C.c_double(rot_eps), C.c_double(trans_eps),
-                       C.c_int(n_threads), _p(T), C.byref(res))
+    lib().orc_icp_gicp2(_p(tgt), C.c_int64(tgt.shape[1]), _p(tc), C.c_int64(tgt.shape[0]), _p(src),
+                        C.c_int64(src.shape[1]), _p(sc), C.c_int64(src.shape[0]), _p(T0), C.c_float(max_dist),
+                        C.c_int(max_iter), C.c_int(fixed_iters), C.c_double(rot_eps), C.c_double(trans_eps),
+                        C.c_int(stop_rule), C.c_double(float(np.float32(rel_fitness))), C.c_double(float(np.float32(rel_rmse))),
+                        C.c_int(n_threads), _p(T), C.byref(res))
     return T.reshape(4, 4), res
 
 

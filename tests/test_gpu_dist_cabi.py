@@ -207,3 +207,42 @@ def test_failing_transport_returns_an_error_instead_of_hanging():
     with pytest.raises(capi.RegError) as e:
         capi.Registration(_params()).dist_register(np.eye(4))
     assert e.value.status == 5      # REG_NOT_CONFIGURED: reg_dist_init first
+
+
+def test_collective_that_never_completes_times_out_instead_of_hanging(monkeypatch):
+    """the waits behind the first all-gather (slice sizes), in reg_dist_finish and in reg_dist_shutdown had no
+    deadline.  A transport whose all_gather ENQUEUES a host function that blocks the stream (a peer that died in the middle of a
+    collective looks like this: no fault, the stream just never drains) must end in REG_DEVICE_ERROR after O3D_DIST_TIMEOUT_S."""
+    import ctypes as C
+    import time
+    hip = C.CDLL("libamdhip64.so")
+    release = threading.Event()
+    HOSTFN = C.CFUNCTYPE(None, C.c_void_p)
+
+    @HOSTFN
+    def blocker(_):
+        release.wait(timeout=20.0)
+
+    def all_gather(send, recv, nbytes, stream):
+        # "rank 1" never sends: the copy of our own block is enqueued, then the stream is parked
+        hip.hipLaunchHostFunc(C.c_void_p(stream), blocker, None)
+        return 0
+
+    monkeypatch.setenv("O3D_DIST_TIMEOUT_S", "0.5")
+    sc = synth.make_scene(4000, 40000, seed=95)
+    reg = capi.Registration(_params(fixed=5))
+    reg.set_target(sc.tgt_xyz, sc.tgt_nrm)
+    reg.set_source(sc.src_xyz, sc.src_nrm)
+    reg.dist_init_custom(lambda *a: 0, all_gather, 0, 2)
+    t0 = time.time()
+    with pytest.raises(capi.RegError) as e:
+        reg.dist_register(np.eye(4))
+    assert e.value.status == 8 and "deadline" in str(e.value)      # REG_DEVICE_ERROR, by the deadline
+    assert time.time() - t0 < 10.0
+    t0 = time.time()
+    reg.dist_shutdown()          # the stream is still parked: the shutdown gives up on it within its deadline as well
+    assert time.time() - t0 < 10.0
+    release.set()
+    import torch
+    torch.cuda.synchronize()
+    reg.close()

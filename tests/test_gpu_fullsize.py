@@ -110,9 +110,20 @@ def _full_size_case(n_src, n_tgt, seed):
     # kernel's own ids / d2 / weights (what iteration 19 used) ...
     T, res = reg.register(np.eye(4))
     assert res.iterations == ITERS
+    assert res.n_tail_launches >= 1 and res.n_tail_iterations >= 5     # the settled tail ran in the persistent kernel
     last_ids, last_d2, last_w = reg.correspondences()
-    # ... the pose before the last update is not exported, so the last iteration is replayed at the final T_iter on both
-    # sides (one more linearisation: iteration 20's matches), and the fused kernel's output is checked for consistency
+    # ... round 3: reg_result.T_iter_prev is the pose iteration 19 actually RAN at, so the persistent tail kernel's OWN output
+    # (temporal-coherence shortcut, its own searches, band classification + exact limit) is compared bit for bit with the
+    # oracle evaluated at that pose -- not a replay on the select-based path
+    T_prev = np.array(res.T_iter_prev, np.float32).reshape(4, 4).T.copy()
+    o_ids, o_d2, o_w, oA, ob, o_err, o_kept = side.linearize(T_prev)
+    assert np.array_equal(last_ids, o_ids), f"tail kernel, last iteration: {(last_ids != o_ids).sum()} ids differ"
+    assert np.array_equal(last_d2.view(np.uint32), o_d2.view(np.uint32)), "tail kernel, last iteration: d2 not bit-exact"
+    assert np.array_equal(last_w, o_w), f"tail kernel, last iteration: {(last_w != o_w).sum()} weights differ"
+    assert res.n_inliers == o_kept
+    H_last = np.array(res.H_last, np.float32).reshape(6, 6)
+    assert np.abs(H_last - oA).max() <= 1e-6 * np.abs(oA).max()
+    # and one more linearisation at the final pose on the select-based path (iteration 20's matches)
     T_last = np.array(res.T_iter_last, np.float32).reshape(4, 4).T.copy()
     matched, kept = _compare(reg, side, T_last, "last iteration")
     assert matched >= matched0 and kept > 0.85 * matched
@@ -154,6 +165,13 @@ def test_c4_map_20M_table_build_and_slice_ids_bit_exact():
     reg.prepare(np.eye(4))
     _compare(reg, side, np.eye(4, dtype=np.float32), "c4 whole reading, iteration 0")
     T, res = reg.register(np.eye(4))
+    # the tail kernel's own last iteration at the pose it ran at (see _full_size_case)
+    last_ids, last_d2, last_w = reg.correspondences()
+    T_prev = np.array(res.T_iter_prev, np.float32).reshape(4, 4).T.copy()
+    o_ids, o_d2, o_w, *_ = side.linearize(T_prev)
+    assert res.n_tail_launches >= 1
+    assert np.array_equal(last_ids, o_ids) and np.array_equal(last_d2.view(np.uint32), o_d2.view(np.uint32))
+    assert np.array_equal(last_w, o_w)
     T_last = np.array(res.T_iter_last, np.float32).reshape(4, 4).T.copy()
     _compare(reg, side, T_last, "c4 whole reading, last iteration")
     et, er = synth.pose_error(T, sc.T_true)
@@ -201,3 +219,50 @@ def test_c2_full_size_gicp_registration_vs_oracle():
     ids_o, d2_o = tree.knn(sc.src_xyz, T_last, max_dist=0.5, n_threads=NT)
     agree = float((gids == ids_o).mean())
     assert agree > 0.995, agree
+
+
+def test_c5_eight_full_size_c2_registrations_in_parallel_threads():
+    """BASELINE configs[4] on ONE GPU: 8 independent handles, each with its own stream, registering 8 different full-size C2
+    problems (seed + i) at the same time from 8 host threads -- one of them at a time owns the device's persistent-tail
+    lock, the others take the three-launch iteration.  Every pose within 1e-4 m / 1e-4 rad of the oracle's for ITS problem."""
+    import threading
+    n_src, n_tgt, K = 100_000, 1_000_000, 8
+    scenes = [synth.make_scene(n_src, n_tgt, seed=4321 + i) for i in range(K)]
+    regs = []
+    for sc in scenes:
+        p = capi.shipped_params()
+        p.use_xicp = 0
+        p.fixed_iters = ITERS
+        r = capi.Registration(p)
+        r.set_target(sc.tgt_xyz, sc.tgt_nrm)
+        r.set_source(sc.src_xyz, sc.src_nrm)
+        regs.append(r)
+    out = [None] * K
+    errs = []
+    start = threading.Barrier(K)
+
+    def work(i):
+        try:
+            start.wait()
+            for _ in range(3):   # several rounds: the lock changes hands
+                out[i] = regs[i].register(np.eye(4))
+        except Exception as e:   # noqa: BLE001
+            errs.append((i, repr(e)))
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(K)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    n_tail = 0
+    for i, sc in enumerate(scenes):
+        T, res = out[i]
+        assert res.iterations == ITERS
+        n_tail += int(res.n_tail_launches > 0)
+        To, ores = orc.icp_p2pl(sc.tgt_xyz, sc.tgt_nrm, sc.src_xyz, sc.src_nrm, max_dist=0.5, trim_ratio=0.9,
+                                max_normal_angle=1.57, fixed_iters=ITERS, n_threads=NT)
+        dt, dr = synth.pose_error(T, To)
+        assert dt <= 1e-4 and dr <= 1e-4, (i, dt, dr)
+        regs[i].close()
+    assert n_tail >= 1

@@ -252,3 +252,20 @@ def test_hybrid_search_normals_follow_open3d_estimate_normals_semantics():
         worst = max(worst, ang)
         n_checked += 1
     assert n_checked > 500 and worst < 1e-3, (n_checked, worst)
+
+
+def test_smooth_normals_rejects_a_neighbour_id_beyond_the_cloud():
+    """an id >= n used to be read from orig[3 * id] on the device; it is now reported as REG_BAD_ARGUMENT."""
+    rng = np.random.default_rng(3)
+    n, k = 500, 6
+    normals = rng.normal(size=(n, 3)).astype(np.float32)
+    ids = rng.integers(0, n, size=(n, k)).astype(np.int32)
+    ids[123, 2] = n
+    reg = capi.Registration(capi.default_params())
+    with pytest.raises(capi.RegError) as e:
+        reg.smooth_normals(normals, ids)
+    assert e.value.status == 6
+    ids[123, 2] = n - 1
+    out, passes = reg.smooth_normals(normals, ids)
+    assert np.isfinite(out).all() and passes >= 1
+    reg.close()
