@@ -422,8 +422,10 @@ reg_status reg_dist_shutdown(reg_handle* h) {
     //  rather than destroyed -- ncclCommDestroy would wait for them)
     const bool drained = !h->stream || dist_stream_wait(h, d->timeout_s, "reg_dist_shutdown") == REG_OK;
     if (d->use_rccl && d->comm && drained) (void)g_rccl.CommDestroy(d->comm);
-    d->counts.release();
-    if (d->h_count) (void)hipHostFree(d->h_count);
+    if (drained) {
+        d->counts.release();
+        if (d->h_count) (void)hipHostFree(d->h_count);
+    }   // else: hipFree / hipHostFree wait for the device, i.e. for the stuck stream -- the few bytes are abandoned with it
     delete d;
     h->dist = nullptr;
     h->dist_ranks = 0;

@@ -1125,7 +1125,7 @@ def test_persistent_tail_equals_three_launch_iteration_and_select_based_path():
     path (disable_fused) give the same iteration counts, ids, d2, weights (bit for bit) and poses -- on sizes that exercise
     1 .. 256 workgroups of the tail kernel, partially filled octets, narrow and wide bands (fixed count from iteration 2 on),
     checker mode, maxDist-limited matching and no trimming at all."""
-    cases = [(37, 50, dict(fixed_iters=8)), (3000, 30000, dict(fixed_iters=12)), (24000, 240000, dict()),
+    cases = [(37, 50, dict(fixed_iters=8, max_dist=float("inf"))), (300, 2000, dict(fixed_iters=9, max_dist=2.0)), (3000, 30000, dict(fixed_iters=12)), (24000, 240000, dict()),
              (24000, 240000, dict(fixed_iters=15, trim_ratio=0.6)), (9000, 90000, dict(fixed_iters=10, use_trimmed=0)),
              (9000, 90000, dict(max_dist=0.12)), (70001, 400000, dict(fixed_iters=14))]
     for n_src, n_tgt, kw in cases:
