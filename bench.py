@@ -185,7 +185,7 @@ def pmc_traffic(workload, dom):
                 continue
             for kname, kv in pj["kernels"].items():
                 if kname.startswith(dom):
-                    return kv["hbm_bytes_per_launch_corrected"], (f"STATIC: read from the committed profiles/{name} (rocprofv3 --pmc passes of "
+                    return kv.get("hbm_bytes_per_iteration_corrected", kv["hbm_bytes_per_launch_corrected"]), (f"STATIC: read from the committed profiles/{name} (rocprofv3 --pmc passes of "
                                                                   "this command, 2*FETCH_SIZE + WRITE_SIZE per launch), not measured in this run")
         except (OSError, KeyError, ValueError):
             pass

@@ -61,6 +61,10 @@ constexpr int kTailBins = 1024;        // bins of the one-level select inside th
 #ifndef O3D_TAIL_STAMPS
 #define O3D_TAIL_STAMPS 0
 #endif
+#ifndef O3D_TAIL_G4
+#define O3D_TAIL_G4 0   // 1: 4 lanes per point in the tail kernel's searches when a workgroup has more failures than 8-lane groups
+                        // (measured round 3: no gain at C2 / C3 / C4 -- the early iterations are not bound by the number of rounds)
+#endif
 #if O3D_TAIL_STAMPS
 #define TAIL_STAMP(i)                                                      \
     do {                                                                   \
@@ -532,10 +536,15 @@ k_tail(const float4* __restrict__ src, const float4* __restrict__ src_nrm, IterS
         TAIL_STAMP(0);   // shortcut test
         const int nf = (int)misc[0];
         n_searched += (t == 0) ? (unsigned)nf : 0u;
-        // ---- this workgroup's own searches: 8 lanes per point, kTailGroups points per round
-        {
-            const int sub = t & 7, grp = t >> 3;
-            for (int base = 0; base < nf; base += kTailGroups) {
+        // ---- this workgroup's own searches: G lanes per point.  Settled iterations have a few dozen failures per workgroup:
+        //      8 lanes per point, one round.  The first iterations after the large corrections have hundreds (every point moved
+        //      by millimetres): 4 lanes per point then -- twice the searches in flight per round; the rounds are chains of
+        //      dependent round trips, not candidate-bound, so halving their number pays for the longer scans per lane.
+        auto search_rounds = [&](auto gtag) {
+            constexpr int G = decltype(gtag)::value;
+            constexpr int kGroups = kTailThreads / G;
+            const int sub = t & (G - 1), grp = t / G;
+            for (int base = 0; base < nf; base += kGroups) {
                 const int fi = base + grp;
                 if (fi < nf) {   // uniform inside a group
                     const int slot = (int)fail[fi];
@@ -544,7 +553,7 @@ k_tail(const float4* __restrict__ src, const float4* __restrict__ src_nrm, IterS
                     const int hv = (int)hnt[slot];
                     int lvl;
                     float cov2;
-                    const Best bb = nearest_group<8, O3D_COH_PRUNE != 0, true>(g, p2, sub, -1, &lvl, seg_lds + grp * kSegWords<8>,
+                    const Best bb = nearest_group<G, O3D_COH_PRUNE != 0, true>(g, p2, sub, -1, &lvl, seg_lds + grp * kSegWords<G>,
                                                                                hv >= 2 ? hv - 2 : -1, &cov2, cfg.slack);
                     if (sub == 0) {
                         hnt[slot] = (uint8_t)(lvl + 1);
@@ -566,7 +575,13 @@ k_tail(const float4* __restrict__ src, const float4* __restrict__ src_nrm, IterS
                     }
                 }
             }
-        }
+        };
+#if O3D_TAIL_G4
+        if (nf > kTailThreads / 8)
+            search_rounds(std::integral_constant<int, 4>());
+        else
+#endif
+            search_rounds(std::integral_constant<int, 8>());
         __syncthreads();   // search results visible to the owners; the segment lists are dead: the union becomes the factor table
         TAIL_STAMP(1);   // own searches
         // ---- weights, class, factor row of this thread's points (coh_epilogue without the global writes)

@@ -20,6 +20,7 @@
 #include <limits>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 using namespace o3dreg;

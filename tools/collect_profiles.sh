@@ -2,9 +2,9 @@
 # Collects the round's profile artefacts on the GPU box (run through gpurun from the repo root):
 #   kernel trace + stats of the default bench command (C3 headline, no secondary objects), FETCH_SIZE / WRITE_SIZE PMC passes
 #   (separate runs, counters + kernel trace only, as the MI355X guide prescribes), and the FETCH_SIZE calibration.
-# usage: bash tools/collect_profiles.sh [r02]
+# usage: bash tools/collect_profiles.sh [r03]
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/profiles_$TAG
 rm -rf $OUT && mkdir -p $OUT

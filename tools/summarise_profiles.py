@@ -10,7 +10,7 @@ class glob:  # newest first: gpurun merges new runs next to older ones
 
 
 out = sys.argv[1]
-TAG = sys.argv[2] if len(sys.argv) > 2 else "r02"          # round tag of the files written under profiles/
+TAG = sys.argv[2] if len(sys.argv) > 2 else "r03"          # round tag of the files written under profiles/
 WL = sys.argv[3] if len(sys.argv) > 3 else "c3"            # workload the bench command ran (bench.py default: c3)
 dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -44,7 +44,7 @@ for k, known in (("k_stream", float(1 << 30)), ("k_gather16", float((1 << 30) //
 summary = {"command": "python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras", "workload": WL, "calibration": cal, "kernels": {}}
 stream_ratio = cal.get("k_stream", {}).get("reported_over_known", 0.5)
 for k in sorted(set(fetch) | set(write)):
-    if not any(x in k for x in ("k_match", "k_iter_fused", "k_coh_", "k_linearize", "k_reduce_update", "k_select", "k_hist")):
+    if not any(x in k for x in ("k_match", "k_iter_fused", "k_coh_", "k_linearize", "k_reduce_update", "k_select", "k_hist", "k_tail")):
         continue
     f = fetch.get(k, {}).get("FETCH_SIZE", [])
     w = write.get(k, {}).get("WRITE_SIZE", [])
@@ -58,6 +58,19 @@ for k in sorted(set(fetch) | set(write)):
         "hbm_bytes_per_launch_corrected": ((sum(f) / len(f)) * 1024.0 / stream_ratio if f else 0.0) + ((sum(w) / len(w)) * 1024.0 if w else 0.0),
     }
 ks = summary["kernels"]
+# the persistent tail kernel: one launch runs many iterations -> per-iteration figures from the bench line of the same command
+tail_its = None
+try:
+    for line in open(os.path.join(out, "bench_trace.log")):
+        if line.startswith('{"metric"'):
+            tail_its = json.loads(line)["kernels"]["k_tail"]["iterations"]
+except (OSError, KeyError, ValueError):
+    pass
+for k, v in ks.items():
+    if k.startswith("k_tail") and tail_its:
+        v["iterations_per_launch"] = tail_its
+        v["avg_us_per_iteration"] = (v["avg_us"] or 0) / tail_its
+        v["hbm_bytes_per_iteration_corrected"] = v["hbm_bytes_per_launch_corrected"] / tail_its
 chk = next((v for k, v in ks.items() if k.startswith("k_coh_check")), None)
 sea = next((v for k, v in ks.items() if k.startswith("k_coh_search")), None)
 if chk and sea and chk["launches"]:
