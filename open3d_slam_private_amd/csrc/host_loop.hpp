@@ -641,8 +641,28 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
     h->last_tail_iters = 0;
     for (;;) {
         if (tail_seq) {
-            s = wait_seq(h, tail_seq);
-            if (s != REG_OK) return s;
+            // The tail reports once, when it leaves.  It leaves at once, WITHOUT a report, when a sequence enqueued in front of
+            // it ended the loop (checker mode: the last select-based iteration converged while the tail was already queued):
+            // that sequence's own report says so, no need to wait for the stream to drain.
+            for (unsigned spins = 0;; ++spins) {
+                const unsigned long long m = mirror_seq(h);
+                if (m >= tail_seq) break;
+                if (m + 1 == tail_seq) {
+                    // (the RECORD of that sequence, not the mirror's loose fields: the tail's own mirror words -- done = 1 --
+                    //  become visible before its sequence word does)
+                    const HostMirror::SeqRecord* rec = &mir->ring[(tail_seq - 1) % kSeqRing];
+                    if (__atomic_load_n(&rec->seq, __ATOMIC_ACQUIRE) == tail_seq - 1 && (rec->done || rec->stall)) break;
+                }
+                __builtin_ia32_pause();
+                if ((spins & 0xfff) == 0xfff) {
+                    const hipError_t e = hipStreamQuery(h->stream);
+                    if (e == hipSuccess) break;
+                    if (e != hipErrorNotReady) {
+                        h->err = std::string("device fault while waiting for the tail kernel: ") + hipGetErrorString(e);
+                        return REG_DEVICE_ERROR;
+                    }
+                }
+            }
             const bool reported = mirror_seq(h) >= tail_seq;
             unsigned words[4] = {0, 0, 0, 0};
             if (!reported || h->env.coh_stats || mir->status == REG_DEVICE_ERROR)

@@ -468,6 +468,7 @@ __device__ __forceinline__ float scan_level_rows(const Grid& g, const float3 p, 
               nbz = (hiz >> kBrickLog2) - bz0 + 1;
     const int nbxy = nbx * nby;
     const int n_bricks = nbxy * nbz;
+    const bool pk_ok = nbx <= 1024 && nby <= 1024 && nbz <= 1024;
     const unsigned gmask = (1u << G) - 1u;
     // Ball pruning (exact): a bin box holds ~2x the volume of the ball it covers.  Rows whose (y, z) bin interval lies
     // farther than the box radius from the query are skipped and the others are cut to the x-range the ball reaches, in BIN
@@ -485,9 +486,14 @@ __device__ __forceinline__ float scan_level_rows(const Grid& g, const float3 p, 
         const int bi = cb + sub;
         int bid = -1;
         uint32_t m_lo = 0, m_hi = 0;
+        uint32_t bpk = 0;   // this lane's brick inside the box, packed (ix | iy << 8 | iz << 16): the slots below fetch it from
+                            // the owner lane by ONE shuffle instead of decoding the brick number with two integer divisions
+                            // each (~45 of the ~140 VALU instructions a slot cost: the level scans of the first iterations are
+                            // bound by this enumeration, not by their candidates -- profiles/r03_counters_c3_per_dispatch.txt)
         if (bi < n_bricks) {
             const int iz = bi / nbxy, rem = bi - iz * nbxy;
             const int iy = rem / nbx, ix = rem - iy * nbx;
+            bpk = (uint32_t)ix | ((uint32_t)iy << 10) | ((uint32_t)iz << 20);   // (boxes wider than 1024 bricks: decoded below)
             const int bx = bx0 + ix, by = by0 + iy, bz = bz0 + iz;
             const size_t at = ((size_t)bz * g.bdy + by) * g.bdx + bx;
             bid = g.brick_dir[at];
@@ -552,11 +558,17 @@ __device__ __forceinline__ float scan_level_rows(const Grid& g, const float3 p, 
                 const uint32_t o_lo = (uint32_t)__shfl((int)m_lo, gbase + j), o_hi = (uint32_t)__shfl((int)m_hi, gbase + j);
                 const int o_bid = __shfl(bid, gbase + j);
                 const uint32_t o_ex = (uint32_t)__shfl((int)excl, gbase + j);
+                const uint32_t o_pk = (uint32_t)__shfl((int)bpk, gbase + j);
                 if (t < total) {
                     const int r = nth_set_bit64(o_lo, o_hi, (int)((uint32_t)tc - o_ex));   // row = z_local * 8 + y_local
-                    const int bj = cb + j;
-                    const int iz = bj / nbxy, rem = bj - iz * nbxy;
-                    const int iy = rem / nbx, ix = rem - iy * nbx;
+                    int ix = (int)(o_pk & 1023u), iy = (int)((o_pk >> 10) & 1023u), iz = (int)(o_pk >> 20);
+                    if (!pk_ok) {   // group-uniform; an unbounded search over a very large grid
+                        const int bj = cb + j;
+                        iz = bj / nbxy;
+                        const int rem = bj - iz * nbxy;
+                        iy = rem / nbx;
+                        ix = rem - iy * nbx;
+                    }
                     const int bx = bx0 + ix, cy = ((by0 + iy) << kBrickLog2) + (r & 7), cz = ((bz0 + iz) << kBrickLog2) + (r >> 3);
                     int gx0 = max(lox, bx << kBrickLog2), gx1 = min(hix, (bx << kBrickLog2) + kBrickDim - 1);
                     bool keep = true;

@@ -308,3 +308,59 @@ def test_smooth_normals_oracle_follows_the_in_place_recurrence():
         ref[i] = m / np.float32(cnt)
     assert np.array_equal(out, ref)
     assert not np.array_equal(out, nr)
+
+
+def _se3_exp(d):
+    """exp of [w; v] as 4x4 (Rodrigues + left Jacobian), float64 -- the restatement's right-multiplied GICP update."""
+    w, v = np.asarray(d[:3], np.float64), np.asarray(d[3:], np.float64)
+    th = float(np.linalg.norm(w))
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    if th < 1e-10:
+        A, B, Cc = 1.0 - th * th / 6.0, 0.5 - th * th / 24.0, 1.0 / 6.0 - th * th / 120.0
+    else:
+        A, B, Cc = np.sin(th) / th, (1.0 - np.cos(th)) / th ** 2, (th - np.sin(th)) / th ** 3
+    T = np.eye(4)
+    T[:3, :3] = np.eye(3) + A * K + B * K @ K
+    T[:3, 3] = (np.eye(3) + B * K + Cc * K @ K) @ v
+    return T
+
+
+def test_gicp_open3d_convergence_criteria_against_a_python_restatement_of_the_loop():
+    """B1 / R12 (PARITY UNPINNED: Open3D 0.15.1 is an un-vendored dependency of the reference).  open3d_slam's
+    RegistrationIcpGeneralized only sets max_iteration_ (open3d_slam/src/CloudRegistration.cpp:16-21,45-52), so Open3D's default
+    ICPConvergenceCriteria ends the loop: RegistrationICP evaluates the correspondences, updates, evaluates again and stops when
+    |fitness - previous| < relative_fitness AND |inlier_rmse - previous| < relative_rmse (1e-6 each), else after max_iteration
+    updates.  The C oracle's stop_rule = 1 against a line-by-line Python restatement of that published loop on the oracle's own
+    building blocks (exact kd-tree matches, float64 normal equations): same number of updates, same flags, same pose."""
+    sc = synth.make_scene(3000, 30000, seed=15)
+    tree = orc.KdTree(sc.tgt_xyz)
+    n = sc.src_xyz.shape[0]
+    for max_iter, rel in ((40, 1e-6), (3, 1e-6), (40, 1e-3)):
+        T = np.eye(4)
+        fit_prev = rmse_prev = 0.0
+        updates, converged, maxed = 0, False, False
+        for it in range(max_iter + 1):
+            Tf = T.astype(np.float32)
+            ids, d2 = tree.knn(sc.src_xyz, Tf, max_dist=0.5)
+            H, b, e, cnt = orc.gicp_normal_eq(sc.src_xyz, sc.src_cov, sc.tgt_xyz, sc.tgt_cov, Tf, ids)
+            fit = cnt / float(np.float32(n))
+            rmse = float(np.sqrt(d2[ids >= 0].astype(np.float64).sum() / cnt))
+            if it >= 1 and abs(fit - fit_prev) < float(np.float32(rel)) and abs(rmse - rmse_prev) < float(np.float32(rel)):
+                converged = True
+                break
+            if it >= max_iter:
+                maxed = True
+                break
+            fit_prev, rmse_prev = fit, rmse
+            dl = np.linalg.solve(np.asarray(H, np.float64).reshape(6, 6), -np.asarray(b, np.float64))
+            T = T @ _se3_exp(dl)
+            updates += 1
+        To, res = orc.icp_gicp(sc.tgt_xyz, sc.tgt_cov, sc.src_xyz, sc.src_cov, np.eye(4), max_dist=0.5, max_iter=max_iter,
+                               stop_rule=1, rel_fitness=rel, rel_rmse=rel)
+        assert res.iterations == updates, (max_iter, rel, res.iterations, updates)
+        assert bool(res.converged) == converged and bool(res.max_iter_reached) == maxed
+        dt, dr = synth.pose_error(To, T)
+        assert dt <= 1e-5 and dr <= 1e-5, (dt, dr)
+    # the eps rule (stop_rule 0) ends on the size of the update instead: a different number of iterations on the same clouds
+    _, r0 = orc.icp_gicp(sc.tgt_xyz, sc.tgt_cov, sc.src_xyz, sc.src_cov, np.eye(4), max_dist=0.5, max_iter=40)
+    assert r0.converged and r0.iterations >= 2
