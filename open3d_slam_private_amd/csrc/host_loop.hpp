@@ -399,10 +399,10 @@ static bool tail_eligible(const reg_handle* h) {
 
 // Enqueue the tail for at most `max_iters` iterations; the kernel reports ONCE (sequence h->seq) when it leaves.
 static reg_status enqueue_tail(reg_handle* h, const TailPlan& pl, int max_iters, bool want_w) {
-    HIPCHK(h, h->i_tail_sync.reserve(kTailSyncWords * 4));
-    HIPCHK(h, h->i_tail_rows.reserve((size_t)2 * pl.grid * kTailRow * 8));
-    HIPCHK(h, h->i_tail_band.reserve((size_t)2 * pl.grid * kTailWgBand * kTailRec * 4));
-    HIPCHK(h, hipMemsetAsync(h->i_tail_sync.p, 0, kTailSyncWords * 4, h->stream));
+    HIPCHK(h, h->i_tail_sync.reserve(kTailSyncBytes));
+    HIPCHK(h, h->i_tail_rows.reserve((size_t)2 * pl.grid * kTailHistRow * 8));
+    HIPCHK(h, h->i_tail_band.reserve((size_t)2 * kTailBandCap * kTailRec * 4));
+    HIPCHK(h, hipMemsetAsync(h->i_tail_sync.p, 0, kTailSyncBytes, h->stream));
     const FilterCfg f = make_filter_cfg(h, 0);
     TailCfg cfg;
     cfg.n = h->n;

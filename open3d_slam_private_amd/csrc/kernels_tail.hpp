@@ -18,14 +18,19 @@
 //     fails cluster in space (clutter, thin structures), the interleave spreads a cluster over all CUs of the XCD, so
 //     every workgroup searches ITS OWN few failures (8 lanes per point, nearest_group as in k_coh_search) -- no queue,
 //     no stealing, no second grid-wide rendezvous;
-//   * per iteration ONE all-to-all exchange: every workgroup publishes its 32 partial sums (fp64) and its band records
-//     (write-through stores), arrives on a per-XCD-class counter, and then EVERY workgroup redundantly reduces the same
-//     rows in the same order, verifies the predicted band with the exact counts, selects the exact quantile inside it,
-//     adds the surviving band records, solves the 6x6 system, updates the pose and runs the checkers -- identical
-//     arithmetic on identical inputs, hence identical poses on every CU without a broadcast and without a
-//     one-workgroup kernel.  Sum order is fixed (workgroup rows in index order): results are run-to-run reproducible.
-//   * the stall / repair contract is unchanged: a failed band verification (or an overflowing band) leaves the kernel
-//     with `stall` set; the host repairs that iteration on the select-based path and launches the tail again.
+//   * per iteration ONE all-to-all exchange.  Every wave adds its 32 partial sums (fp64, reduced over the wave by a halving
+//     butterfly: no LDS table) to the accumulator row of its XCD class with ONE 256-byte memory-side fp64 atomic instruction;
+//     band records go into one global list (slot = a returning atomic per wave that has any, issued before the sums are
+//     formed so that its latency hides behind them).  The workgroup then arrives on its class counter.  After the rendezvous
+//     EVERY workgroup reads the same 8 x 32 sums, the record count and -- speculatively, in the same batch of loads -- one
+//     record per thread: one dependent memory hop instead of three (rows -> offsets -> records), 2 KB + the records instead
+//     of 67 KB per workgroup.  Then every workgroup redundantly verifies the predicted band with the exact counts, selects
+//     the exact quantile inside it, adds the surviving records, solves the 6x6 system, updates the pose and runs the
+//     checkers -- identical arithmetic on identical inputs, hence identical poses on every CU without a broadcast and
+//     without a one-workgroup kernel.  (The accumulation order of the atomics is not fixed: A, b are equal up to the fp64
+//     summation order from run to run, as with the accumulator replicas of the three-launch iteration; every workgroup
+//     reads the SAME accumulated values, which is what the redundant solve needs.)  Accumulators and counters live in a
+//     ring of four epochs; workgroup 0 clears the set two epochs ahead.
 // Hand-off form (MI355X guide, "Valid forms"): every handed-off byte is stored with an agent-scope relaxed atomic store
 // (write-through, sc1), every storing wave drains (s_waitcnt vmcnt(0)) before the workgroup barrier, ONE lane then adds
 // to the arrival counter; the consumer polls with relaxed agent-scope loads from one wave, (optionally) fences, joins the
@@ -43,14 +48,18 @@ constexpr int kTailThreads = O3D_TAIL_THREADS;   // 8 waves = 2 per SIMD: 256 VG
 constexpr int kTailSlots = 1024;        // reading-point slots per workgroup: thread t owns slots t and t + 512
 constexpr int kTailPts = kTailSlots / kTailThreads;
 constexpr int kTailBandCap = 1024;     // band records one iteration may hold in all (more: stall, select-based repair)
-constexpr int kTailWgBand = 32;        // ... and per workgroup (each workgroup publishes into its own region)
 constexpr int kTailRec = 12;           // floats per band record: F0..F5, r, d2, kept, 0, kept d2, 0  (= a factor row)
-constexpr int kTailRow = 66;           // doubles per published row: 32 sums, [32] = band-record count (uint64), [33] pad,
-                                       // [34..65] = 256 one-byte counts: this workgroup's band points per coarse bin (wide bands)
+constexpr int kTailHistRow = 32;       // doubles per workgroup in the coarse-histogram rows (wide bands): 256 one-byte counts
 constexpr int kTailCoarse = 256;       // coarse bins of a wide band (second exchange of the iteration: see k_tail)
 constexpr float kTailWideRel = 0.02f;  // a band wider than this fraction of its lower edge takes the two-exchange form
 constexpr int kTailMaxIters = 64;      // iterations per launch
-constexpr int kTailSyncWords = 256;    // zeroed before every launch: arrival counters, error word, statistics
+constexpr int kTailSyncWords = 256;    // zeroed before every launch: arrival counters, record counters, error word, statistics
+constexpr int kTailRing = 4;           // epochs an accumulator set / record counter lives before it is reused
+constexpr int kTailBandCntWord = 128;  // record counter of epoch e: word [128 + 16 * (e % 4)]
+constexpr int kTailAccRows = 16;       // accumulator rows per epoch: same-address fp64 atomics serialise (~40 ns each, measured:
+                                       // 256 waves on 8 rows cost the exchange 4 us), so one atomic per WORKGROUP on 16 rows
+constexpr int kTailAccDoubles = kTailRing * kTailAccRows * kSums;   // accumulators behind the sync words: [epoch % 4][row][32]
+constexpr int kTailSyncBytes = kTailSyncWords * 4 + kTailAccDoubles * 8;   // the block the host zeroes before every launch
 constexpr int kTailArriveStride = 16;  // arrival counters 64 bytes apart: word [x * 16], x = XCD class 0..7
 constexpr int kTailErrWord = 192;      // != 0: a grid barrier timed out
 constexpr int kTailSearchedWord = 193; // statistics: points searched (summed over iterations and workgroups)
@@ -89,8 +98,8 @@ struct TailCfg {
 // LDS carve-up (dynamic region only; every offset a multiple of 16)
 struct TailLds {
     static constexpr int kRows = 0;                                   // float4 [4][1024]
-    static constexpr int kUnion = kRows + 4 * kTailSlots * 16;      // E table | segment lists | phase-C scratch
-    static constexpr int kUnionBytes = 61440;
+    static constexpr int kUnion = kRows + 4 * kTailSlots * 16;        // segment lists of the searches | ranking keys of the select
+    static constexpr int kUnionBytes = 36864;
     static constexpr int kD2 = kUnion + kUnionBytes;                  // float [1024]
     static constexpr int kFail = kD2 + kTailSlots * 4;              // uint16 [1024]
     static constexpr int kWcls = kFail + kTailSlots * 2;            // uint8 [1024]
@@ -107,12 +116,9 @@ struct TailLds {
     static constexpr int kMirrorBytes = (int)((sizeof(HostMirror) + 15) & ~size_t(15));
     static constexpr int kHist = kMirror + kMirrorBytes;              // uint32 [kTailBins]
     static constexpr int kTotal = kHist + kTailBins * 4;
-    // phase-C view of the union
-    static constexpr int kBt = kUnion;                                // float [kTailBandCap][13]
-    static constexpr int kBk = kBt + kTailBandCap * kCohRow * 4;      // uint64 [kTailBandCap]   (53248 -> +8192 = 61440)
+    static constexpr int kBk = kUnion;                                // uint64 [kTailBandCap] keys of the picked bin's members
 };
 static_assert(TailLds::kBk + kTailBandCap * 8 - TailLds::kUnion <= TailLds::kUnionBytes, "phase-C scratch exceeds the union");
-static_assert(kTailSlots * kCohRow * 4 <= TailLds::kUnionBytes, "factor table exceeds the union");
 static_assert(kTailGroups * kSegWords<8> * 4 <= TailLds::kUnionBytes, "segment lists exceed the union");
 static_assert(TailLds::kTotal <= 160 * 1024, "LDS budget of one CU");
 constexpr int kTailLdsBytes = TailLds::kTotal;
@@ -134,41 +140,6 @@ __device__ __forceinline__ void tail_st_u64(void* p, unsigned long long x) {
 }
 __device__ __forceinline__ unsigned tail_ld_u32(const unsigned* p) {
     return __hip_atomic_load(const_cast<unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Component `comp` of the 32 sums over rows r0, r0 + stride, ... < r1 of a factor table (row pitch kCohRow): fp32 product,
-// fp64 sum in row order.  kBand: only rows whose d2 (entry 7) is <= limit count (the band records that survive the trim).
-// The LDS reads of kU rows are issued together (one by one each iteration paid a full LDS round trip: 64 rows x ~100
-// cycles = 3 us of the 24 us iteration, measured with in-kernel stamps).
-template <bool kBand>
-__device__ __forceinline__ double tail_component_sum(const float* tab, int r0, int r1, int stride, int comp, float limit) {
-    constexpr int kU = 8;
-    int ia, ic;
-    if (comp < 28) {
-        ia = kProdCode.a[comp] >> 2;
-        ic = kProdCode.c[comp] >> 2;
-    } else {
-        ia = 8 + (comp - 28);
-        ic = ia;
-    }
-    double acc = 0.0;
-    for (int r = r0; r < r1; r += kU * stride) {
-        float a[kU], c[kU], d[kU];
-#pragma unroll
-        for (int u = 0; u < kU; ++u) {
-            const int rr = min(r + u * stride, r1 - 1);   // clamped: masked below
-            a[u] = tab[rr * kCohRow + ia];
-            c[u] = tab[rr * kCohRow + ic];
-            d[u] = kBand ? tab[rr * kCohRow + 7] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < kU; ++u) {
-            const bool on = r + u * stride < r1 && (!kBand || d[u] <= limit);
-            const float v = comp < 28 ? a[u] * c[u] : a[u];
-            acc += on ? (double)v : 0.0;
-        }
-    }
-    return acc;
 }
 
 // R8 + R9 of the tail kernel, wave 0 of every workgroup (identical inputs -> identical poses everywhere): Gauss-Jordan on the
@@ -266,13 +237,11 @@ __global__ void __launch_bounds__(kTailThreads)
 k_tail(const float4* __restrict__ src, const float4* __restrict__ src_nrm, IterState* __restrict__ it_g, Grid g,
        const float4* __restrict__ tgt_nrm, FilterCfg f, int* __restrict__ pos_io, float* __restrict__ d2_out,
        float* __restrict__ w_out, uint8_t* __restrict__ hint_g, const float4* __restrict__ cache, unsigned* __restrict__ sync,
-       double* __restrict__ rows_g /* [2][grid][kTailRow] */, float* __restrict__ band_g /* [2][grid][kTailWgBand][12] */,
+       double* __restrict__ hist_g /* [2][grid][kTailHistRow] */, float* __restrict__ band_g /* [2][kTailBandCap][12] */,
        HostMirror* host, TailCfg cfg) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float4* const st_rows = reinterpret_cast<float4*>(lds + TailLds::kRows);            // [row * kTailSlots + slot]
-    float* const E = reinterpret_cast<float*>(lds + TailLds::kUnion);
     uint32_t* const seg_lds = reinterpret_cast<uint32_t*>(lds + TailLds::kUnion);
-    float* const bt = reinterpret_cast<float*>(lds + TailLds::kBt);
     unsigned long long* const bk = reinterpret_cast<unsigned long long*>(lds + TailLds::kBk);
     float* const d2s = reinterpret_cast<float*>(lds + TailLds::kD2);
     uint16_t* const fail = reinterpret_cast<uint16_t*>(lds + TailLds::kFail);
@@ -283,13 +252,14 @@ k_tail(const float4* __restrict__ src, const float4* __restrict__ src_nrm, IterS
     uint32_t* const s_state = reinterpret_cast<uint32_t*>(lds + TailLds::kState);
     IterState* const sit = reinterpret_cast<IterState*>(s_state);
     // misc: [0] failures of this iteration [2] limit bits [3] poll ok [5] band overflow [6] picked bin [7] rank inside it
-    //       [8] its count [9] members gathered
+    //       [8] its count [9] members gathered [10] coarse bin [12] band points (wide)
     uint32_t* const misc = reinterpret_cast<uint32_t*>(lds + TailLds::kMisc);
     uint32_t* const wtot = reinterpret_cast<uint32_t*>(lds + TailLds::kWtot);
     uint32_t* const off = reinterpret_cast<uint32_t*>(lds + TailLds::kOff);
     float* const s_x = reinterpret_cast<float*>(lds + TailLds::kX);
     uint32_t* const mir_w = reinterpret_cast<uint32_t*>(lds + TailLds::kMirror);
     uint32_t* const hist = reinterpret_cast<uint32_t*>(lds + TailLds::kHist);
+    double* const acc_g = reinterpret_cast<double*>(sync + kTailSyncWords);   // [epoch % 4][XCD class][32], zeroed with the sync words
     constexpr int kStateWords = (int)(sizeof(IterState) / 4);
     constexpr int kWaves = kTailThreads / 64;
     static_assert(kStateWords <= kTailThreads && kTailThreads >= 256, "state staging / count scan by the first threads");
@@ -344,19 +314,32 @@ k_tail(const float4* __restrict__ src, const float4* __restrict__ src_nrm, IterS
     unsigned long long stamp_last = __builtin_amdgcn_s_memrealtime();
 #endif
     // (set at the top of every iteration from a loop-VARIANT copy of the thread index: computed once in front of the loop, the
-    //  ~100 row / count / histogram addresses derived from them stayed live across the whole loop -- the compiler spilled them
-    //  around the search and reloaded them, one scratch round trip each, in every phase)
-    int comp = t & (kSums - 1), part = t >> 5, tv = t;
-    constexpr int kParts = kTailThreads / kSums, kRowsPerPart = kTailSlots / kParts;
+    //  addresses derived from them stayed live across the whole loop -- the compiler spilled them around the search and
+    //  reloaded them, one scratch round trip each, in every phase)
+    int tv = t;
 
-    // ---- one all-to-all rendezvous.  Before: every wave has ISSUED its write-through stores of this epoch.  After (true):
-    //      every workgroup's stores of this epoch are visible to agent-scope (sc1) loads.  false: timed out.
-    auto exchange = [&]() -> bool {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
-        __syncthreads();
+    // ---- one all-to-all rendezvous.  Before: every wave has ISSUED its atomics / write-through stores of this epoch.  After
+    //      (true): they are visible to agent-scope (sc1) loads of every workgroup.  false: timed out.
+    auto exchange = [&](unsigned set) -> bool {
+        if (blockIdx.x == 0) {   // the accumulator set / record counter two epochs ahead (nobody reads or adds to them now)
+            const unsigned nxt = (epoch + 2u) & (kTailRing - 1);
+            if (t < kTailAccRows * kSums) tail_st_f64(acc_g + (size_t)nxt * kTailAccRows * kSums + tv, 0.0);
+            if (t == 0) __hip_atomic_store(&sync[kTailBandCntWord + 16 * nxt], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave drains its write-through stores (records, histograms)
+        __syncthreads();                                    // ... and the waves' partial sums are in LDS (publish_sums)
         ++epoch;
-        if (t == 0) __hip_atomic_fetch_add(&sync[xcls * kTailArriveStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (wave == 0) {
+            // the workgroup's 32 sums: ONE 256-byte fp64 atomic instruction into one of kTailAccRows rows of set `set`
+            if (lane < kSums) {
+                double v = 0.0;
+#pragma unroll
+                for (int w2 = 0; w2 < kWaves; ++w2) v += sh[w2][lane];
+                const int row = (int)(blockIdx.x & 7) * (kTailAccRows / 8) + (int)((blockIdx.x >> 3) & (kTailAccRows / 8 - 1));
+                unsafeAtomicAdd(acc_g + ((size_t)set * kTailAccRows + row) * kSums + lane, v);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(&sync[xcls * kTailArriveStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned target = epoch * cnt_lane;
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
             bool okp = false;
@@ -376,52 +359,18 @@ k_tail(const float4* __restrict__ src, const float4* __restrict__ src_nrm, IterS
         __syncthreads();
         return misc[3] != 0u;
     };
-    // ---- the 32 component sums of this workgroup's factor table E -> its row of buffer `buf` (thread t owns component
-    //      t & 31 of the rows of part t >> 5); `count` goes into the row's count slot
-    auto publish_sums = [&](int buf, unsigned count) {
-        double acc = tail_component_sum<false>(E, part * kRowsPerPart, (part + 1) * kRowsPerPart, 1, comp, 0.f);
-        acc += __shfl_xor(acc, 32);
-        if (lane < kSums) sh[wave][lane] = acc;
-        __syncthreads();
-        double* row = rows_g + ((size_t)buf * nwg + blockIdx.x) * kTailRow;
-        if (t < kSums) {
-            double v = 0.0;
-#pragma unroll
-            for (int w2 = 0; w2 < kWaves; ++w2) v += sh[w2][t];
-            tail_st_f64(row + tv, v);
-        }
-        if (t == 32) tail_st_u64(row + 32, (unsigned long long)count);
+    // ---- this wave's 32 partial sums -> LDS (halving butterfly over the wave, 32 shuffles: no factor table); exchange() adds
+    //      the workgroup's total to the accumulators
+    auto publish_sums = [&](double (&v)[kSums]) {
+        wave_reduce32(v);
+        if ((lane & 1) == 0) sh[wave][lane >> 1] = v[0];
     };
-    // ---- every workgroup's row of buffer `buf`, summed in workgroup order -> tot (LDS); the band-record counts -> off[]
-    //      (exclusive prefix, off[256] = total; misc[5] set when a workgroup's region overflowed)
-    auto reduce_rows = [&](int buf, bool add) {
-        constexpr int kRowsMax = 256 / kParts;   // <= 16 rows per part: the grid has <= 256 workgroups
-        const double* rbase = rows_g + (size_t)buf * nwg * kTailRow;
-        double v16[kRowsMax];
-#pragma unroll
-        for (int u = 0; u < kRowsMax; ++u) {   // all of this thread's loads in flight together
-            const int b2 = part + kParts * u;
-            v16[u] = tail_ld_f64(rbase + (size_t)(b2 < nwg ? b2 : 0) * kTailRow + comp);
-        }
-        unsigned cntb = 0;
-        if (t < 256) cntb = (unsigned)tail_ld_u64(rbase + (size_t)(tv < nwg ? tv : 0) * kTailRow + 32);
-        double acc = 0.0;
-#pragma unroll
-        for (int u = 0; u < kRowsMax; ++u) acc += (part + kParts * u < nwg) ? v16[u] : 0.0;
-        acc += __shfl_xor(acc, 32);
-        if (lane < kSums) sh[wave][lane] = acc;
-        if (t < 256) {   // exclusive prefix of the workgroups' band counts (waves 0-3)
-            if (t >= nwg) cntb = 0;
-            if (cntb > (unsigned)kTailWgBand) misc[5] = 1u;
-            unsigned incl = cntb;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const unsigned v = (unsigned)__shfl_up((int)incl, o);
-                if (lane >= o) incl += v;
-            }
-            if (lane == 63) wtot[wave] = incl;
-            off[t] = incl - cntb;   // wave-local for now
-        }
+    // ---- the kTailAccRows accumulator rows of set `set`, summed in row order -> tot (LDS)
+    auto reduce_sums = [&](unsigned set, bool add) {
+        static_assert(kTailAccRows * kSums == kTailThreads, "one accumulator entry per thread");
+        double a = tail_ld_f64(acc_g + (size_t)set * kTailAccRows * kSums + tv);   // thread t: row t >> 5, component t & 31
+        a += __shfl_xor(a, 32);
+        if (lane < kSums) sh[wave][lane] = a;   // (wave 0 consumed the partial sums in here before exchange() let anybody through)
         __syncthreads();
         if (t < kSums) {
             double v = 0.0;
@@ -429,54 +378,57 @@ k_tail(const float4* __restrict__ src, const float4* __restrict__ src_nrm, IterS
             for (int w2 = 0; w2 < kWaves; ++w2) v += sh[w2][t];
             tot[t] = add ? tot[t] + v : v;
         }
-        if (t < 256) {
-            unsigned base = 0;
-#pragma unroll
-            for (int w2 = 0; w2 < 4; ++w2) base += w2 < wave ? wtot[w2] : 0u;
-            off[t] += base;
-            if (t == 255) off[256] = wtot[0] + wtot[1] + wtot[2] + wtot[3];
-        }
         __syncthreads();
     };
-    // ---- band records of this thread's points (those with `mine[u]`) into the workgroup's region of buffer `buf`, in a
-    //      fixed order (slot half, wave, lane); returns the workgroup's record count (contains one __syncthreads)
-    auto publish_records = [&](int buf, const bool (&mine)[kTailPts], const float (&rF)[kTailPts][7], const float (&md2v)[kTailPts],
-                               const float (&wv)[kTailPts]) -> unsigned {
+    // ---- one factor row (F, r; fp32 products, fp64 sums) into the 32 running sums
+    auto accumulate = [&](double (&v)[kSums], const float (&F)[7], float md2) {
+        int k = 0;
+#pragma unroll
+        for (int a6 = 0; a6 < 6; ++a6)
+#pragma unroll
+            for (int c6 = a6; c6 < 6; ++c6) v[k++] += (double)(F[a6] * F[c6]);
+#pragma unroll
+        for (int a6 = 0; a6 < 6; ++a6) v[21 + a6] += (double)(F[a6] * F[6]);
+        v[27] += (double)(F[6] * F[6]);
+        v[28] += 1.0;            // kept
+        v[30] += (double)md2;    // kept d2
+    };
+    // ---- band records of this thread's points (those with `mine[u]`) into the global list of buffer `buf`: one returning
+    //      atomic per wave that has any (the slot order is the atomics' order: the same for every reader)
+    auto reserve_records = [&](unsigned set, const bool (&mine)[kTailPts], unsigned (&slot)[kTailPts]) {
         unsigned long long bal[kTailPts];
+        unsigned nw = 0;
 #pragma unroll
         for (int u = 0; u < kTailPts; ++u) {
             bal[u] = __ballot(mine[u]);
-            if (lane == 0) wtot[u * kWaves + wave] = (unsigned)__popcll(bal[u]);
+            nw += (unsigned)__popcll(bal[u]);
         }
-        __syncthreads();
-        unsigned total = 0;
-#pragma unroll
-        for (int w2 = 0; w2 < kTailPts * kWaves; ++w2) total += wtot[w2];
+        unsigned base = 0;
+        if (nw != 0u) {   // wave-uniform
+            if (lane == 0) base = atomicAdd(&sync[kTailBandCntWord + 16 * set], nw);
+            base = (unsigned)__shfl((int)base, 0);
+        }
+        unsigned before = 0;
 #pragma unroll
         for (int u = 0; u < kTailPts; ++u) {
-            if (!mine[u]) continue;
-            unsigned before = 0;
-            for (int w2 = 0; w2 < u * kWaves + wave; ++w2) before += wtot[w2];
-            const unsigned slotb = before + (unsigned)__popcll(bal[u] & ((1ull << lane) - 1ull));
-            if (slotb < (unsigned)kTailWgBand) {
-                float* rec = band_g + (((size_t)buf * nwg + blockIdx.x) * kTailWgBand + slotb) * kTailRec;
-                const float kept = wv[u] != 0.f ? 1.f : 0.f;
-                const float v[12] = {rF[u][0], rF[u][1], rF[u][2], rF[u][3], rF[u][4], rF[u][5], rF[u][6], md2v[u], kept, 0.f,
-                                     wv[u] != 0.f ? md2v[u] : 0.f, 0.f};
-#pragma unroll
-                for (int k = 0; k < 6; ++k)
-                    tail_st_u64(rec + 2 * k, ((unsigned long long)__float_as_uint(v[2 * k + 1]) << 32) | __float_as_uint(v[2 * k]));
-            }
+            slot[u] = base + before + (unsigned)__popcll(bal[u] & ((1ull << lane) - 1ull));
+            before += (unsigned)__popcll(bal[u]);
         }
-        return total;
+    };
+    auto store_record = [&](int buf, unsigned slotb, const float (&F)[7], float md2, float w) {
+        if (slotb >= (unsigned)kTailBandCap) return;   // (the count tells every reader that the list overflowed)
+        float* rec = band_g + ((size_t)buf * kTailBandCap + slotb) * kTailRec;
+        const float kept = w != 0.f ? 1.f : 0.f;
+        const float v[12] = {F[0], F[1], F[2], F[3], F[4], F[5], F[6], md2, kept, 0.f, w != 0.f ? md2 : 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            tail_st_u64(rec + 2 * k, ((unsigned long long)__float_as_uint(v[2 * k + 1]) << 32) | __float_as_uint(v[2 * k]));
     };
 
     for (;; ++k_local) {
         // ================= phase A: shortcut test, own searches, factor rows, 32 sums, band records =================
         tv = t;
         asm volatile("" : "+v"(tv));
-        comp = tv & (kSums - 1);
-        part = tv >> 5;
         Xf T;
 #pragma unroll
         for (int k = 0; k < 12; ++k) T.m[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sit->T[k])));   // uniform: SGPRs
@@ -485,7 +437,7 @@ k_tail(const float4* __restrict__ src, const float4* __restrict__ src_nrm, IterS
         // A WIDE band (the trimmed limit still moves by per cents: first iterations after the large corrections) holds
         // thousands of points: too many to hand every workgroup as records.  Two exchanges then: first the certain sums and,
         // per workgroup, the counts of its band points in kTailCoarse coarse bins; every workgroup finds the coarse bin b*
-        // that holds the rank; the band shrinks to that bin -- points in lower bins become certain (a second, delta row),
+        // that holds the rank; the band shrinks to that bin -- points in lower bins become certain (a second, delta sum),
         // points of b* become the records -- and the iteration ends as a narrow one.  Exact for the same reason: bins are
         // an order-preserving function of the fp32 bit pattern of d2.
         const bool wide = trim && band_hi < INFINITY && (band_hi - band_lo) > kTailWideRel * band_lo;
@@ -537,9 +489,7 @@ k_tail(const float4* __restrict__ src, const float4* __restrict__ src_nrm, IterS
         const int nf = (int)misc[0];
         n_searched += (t == 0) ? (unsigned)nf : 0u;
         // ---- this workgroup's own searches: G lanes per point.  Settled iterations have a few dozen failures per workgroup:
-        //      8 lanes per point, one round.  The first iterations after the large corrections have hundreds (every point moved
-        //      by millimetres): 4 lanes per point then -- twice the searches in flight per round; the rounds are chains of
-        //      dependent round trips, not candidate-bound, so halving their number pays for the longer scans per lane.
+        //      8 lanes per point, one round.
         auto search_rounds = [&](auto gtag) {
             constexpr int G = decltype(gtag)::value;
             constexpr int kGroups = kTailThreads / G;
@@ -582,127 +532,141 @@ k_tail(const float4* __restrict__ src, const float4* __restrict__ src_nrm, IterS
         else
 #endif
             search_rounds(std::integral_constant<int, 8>());
-        __syncthreads();   // search results visible to the owners; the segment lists are dead: the union becomes the factor table
+        __syncthreads();   // search results visible to the owners
         TAIL_STAMP(1);   // own searches
-        // ---- weights, class, factor row of this thread's points (coh_epilogue without the global writes)
+        // ---- weights, class, factor row of this thread's points (coh_epilogue without the global writes), accumulated in
+        //      registers: certain rows into the 32 sums, band rows kept for the records
         float rF[kTailPts][7], md2v[kTailPts], wv[kTailPts];
         int clsv[kTailPts];
-#pragma unroll
-        for (int u = 0; u < kTailPts; ++u) {
-            const int sl = t + u * kTailThreads;
-            float row[12];
-#pragma unroll
-            for (int k = 0; k < 12; ++k) row[k] = 0.f;
-#pragma unroll
-            for (int k = 0; k < 7; ++k) rF[u][k] = 0.f;
-            const float4 tq = st_rows[kTailSlots + sl], nn = st_rows[2 * kTailSlots + sl];
-            // passed: the previous match with the distance the check computed; searched: the search's result (both in LDS)
-            const int mpos = valid[u] ? __float_as_int(tq.w) : -1;
-            const float md2 = d2s[sl];
-            float w = 0.f;
-            int cls = 2;   // 0: certainly kept, 1: band, 2: dropped / unmatched
-            if (valid[u] && mpos >= 0) {
-                w = 1.f;
-                if (f.use_maxdist && !(md2 <= f.outlier_max_d2)) w = 0.f;
-                if (f.use_normal) {
-                    const float3 nr = normalize3(xf_rot(T, sn[u].x, sn[u].y, sn[u].z));
-                    const float3 nt = normalize3(make_float3(nn.x, nn.y, nn.z));
-                    float a = nr.x * nt.x;
-                    float bb2 = nr.y * nt.y;
-                    float val = a + bb2;
-                    a = nr.z * nt.z;
-                    val = val + a;
-                    if (val < f.cos_max_angle) w = 0.f;
-                }
-                cls = md2 < band_lo ? 0 : (md2 < band_hi ? 1 : 2);
-                if (w != 0.f && cls != 2) {
-                    // F = [p x n ; n], r = (p - q) . n  (the weight is 1: w * F_a * F_c == F_a * F_c exactly)
-                    float a = p[u].y * nn.z, bq = p[u].z * nn.y;
-                    rF[u][0] = a - bq;
-                    a = p[u].z * nn.x; bq = p[u].x * nn.z;
-                    rF[u][1] = a - bq;
-                    a = p[u].x * nn.y; bq = p[u].y * nn.x;
-                    rF[u][2] = a - bq;
-                    rF[u][3] = nn.x; rF[u][4] = nn.y; rF[u][5] = nn.z;
-                    const float dx = p[u].x - tq.x, dy = p[u].y - tq.y, dz = p[u].z - tq.z;
-                    float r = dx * nn.x;
-                    float t2 = dy * nn.y;
-                    r = r + t2;
-                    t2 = dz * nn.z;
-                    r = r + t2;
-                    rF[u][6] = r;
-                }
-                row[9] = 1.f;                               // matched
-                if (cls == 0) row[11] = 1.f;                // below the band (rank bookkeeping is independent of w)
-                if (w != 0.f && cls == 0) {
-#pragma unroll
-                    for (int k = 0; k < 7; ++k) row[k] = rF[u][k];
-                    row[7] = 1.f;
-                    row[8] = 1.f;                           // kept
-                    row[10] = md2;                          // kept d2
-                }
-            }
-            if (!(valid[u] && mpos >= 0)) d2s[sl] = INFINITY;
-            wcls[sl] = (uint8_t)((w != 0.f && cls != 2 ? 1 : 0) | (cls << 1));
-#pragma unroll
-            for (int k = 0; k < 12; ++k) E[sl * kCohRow + k] = row[k];
-            md2v[u] = md2;
-            wv[u] = w;
-            clsv[u] = cls;
-            if (wide && cls == 1) atomicAdd(&hist[coarse_bin(md2)], 1u);
-        }
+        const unsigned set = epoch & (kTailRing - 1);
         int buf = (int)(epoch & 1u);
-        unsigned my_records = 0;
-        if (!wide) {
-            bool mine[kTailPts];
+        {
+            double v[kSums];
 #pragma unroll
-            for (int u = 0; u < kTailPts; ++u) mine[u] = clsv[u] == 1;
-            my_records = publish_records(buf, mine, rF, md2v, wv);   // (one workgroup barrier inside: E is complete after it)
-        } else {
-            __syncthreads();
-        }
-        TAIL_STAMP(2);   // weights, classes, factor rows
-        if (wide && t < kTailCoarse / 8) {
-            // this workgroup's coarse counts, one byte each (saturated: 255 means "too many", the iteration then stalls)
-            unsigned long long pk = 0ull;
+            for (int k = 0; k < kSums; ++k) v[k] = 0.0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const uint32_t c2 = hist[8 * t + j];
-                hist[8 * t + j] = 0u;
-                pk |= (unsigned long long)min(c2, 255u) << (8 * j);
+            for (int u = 0; u < kTailPts; ++u) {
+                const int sl = t + u * kTailThreads;
+#pragma unroll
+                for (int k = 0; k < 7; ++k) rF[u][k] = 0.f;
+                const float4 tq = st_rows[kTailSlots + sl], nn = st_rows[2 * kTailSlots + sl];
+                // passed: the previous match with the distance the check computed; searched: the search's result (both in LDS)
+                const int mpos = valid[u] ? __float_as_int(tq.w) : -1;
+                const float md2 = d2s[sl];
+                float w = 0.f;
+                int cls = 2;   // 0: certainly kept, 1: band, 2: dropped / unmatched
+                if (valid[u] && mpos >= 0) {
+                    w = 1.f;
+                    if (f.use_maxdist && !(md2 <= f.outlier_max_d2)) w = 0.f;
+                    if (f.use_normal) {
+                        const float3 nr = normalize3(xf_rot(T, sn[u].x, sn[u].y, sn[u].z));
+                        const float3 nt = normalize3(make_float3(nn.x, nn.y, nn.z));
+                        float a = nr.x * nt.x;
+                        float bb2 = nr.y * nt.y;
+                        float val = a + bb2;
+                        a = nr.z * nt.z;
+                        val = val + a;
+                        if (val < f.cos_max_angle) w = 0.f;
+                    }
+                    cls = md2 < band_lo ? 0 : (md2 < band_hi ? 1 : 2);
+                    if (w != 0.f && cls != 2) {
+                        // F = [p x n ; n], r = (p - q) . n  (the weight is 1: w * F_a * F_c == F_a * F_c exactly)
+                        float a = p[u].y * nn.z, bq = p[u].z * nn.y;
+                        rF[u][0] = a - bq;
+                        a = p[u].z * nn.x; bq = p[u].x * nn.z;
+                        rF[u][1] = a - bq;
+                        a = p[u].x * nn.y; bq = p[u].y * nn.x;
+                        rF[u][2] = a - bq;
+                        rF[u][3] = nn.x; rF[u][4] = nn.y; rF[u][5] = nn.z;
+                        const float dx = p[u].x - tq.x, dy = p[u].y - tq.y, dz = p[u].z - tq.z;
+                        float r = dx * nn.x;
+                        float t2 = dy * nn.y;
+                        r = r + t2;
+                        t2 = dz * nn.z;
+                        r = r + t2;
+                        rF[u][6] = r;
+                    }
+                    v[29] += 1.0;                               // matched
+                    if (cls == 0) v[31] += 1.0;                 // below the band (rank bookkeeping is independent of w)
+                    if (w != 0.f && cls == 0) accumulate(v, rF[u], md2);
+                }
+                if (!(valid[u] && mpos >= 0)) d2s[sl] = INFINITY;
+                wcls[sl] = (uint8_t)((w != 0.f && cls != 2 ? 1 : 0) | (cls << 1));
+                md2v[u] = md2;
+                wv[u] = w;
+                clsv[u] = cls;
+                if (wide && cls == 1) atomicAdd(&hist[coarse_bin(md2)], 1u);
             }
-            tail_st_u64(rows_g + ((size_t)buf * nwg + blockIdx.x) * kTailRow + 34 + tv, pk);
+            // the record slots first (a returning atomic: its round trip hides behind the butterfly), then the sums
+            unsigned slot[kTailPts];
+            if (!wide) {
+                bool mine[kTailPts];
+#pragma unroll
+                for (int u = 0; u < kTailPts; ++u) mine[u] = clsv[u] == 1;
+                reserve_records(set, mine, slot);
+            }
+            publish_sums(v);
+            if (!wide) {
+#pragma unroll
+                for (int u = 0; u < kTailPts; ++u)
+                    if (clsv[u] == 1) store_record(buf, slot[u], rF[u], md2v[u], wv[u]);
+            }
         }
-        publish_sums(buf, my_records);
+        TAIL_STAMP(2);   // weights, classes, sums, records
+        if (wide) {
+            __syncthreads();   // the workgroup's coarse counts are complete
+            if (t < kTailCoarse / 8) {
+                // this workgroup's coarse counts, one byte each (saturated: 255 means "too many", the iteration then stalls)
+                unsigned long long pk = 0ull;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t c2 = hist[8 * t + j];
+                    hist[8 * t + j] = 0u;
+                    pk |= (unsigned long long)min(c2, 255u) << (8 * j);
+                }
+                tail_st_u64(hist_g + ((size_t)buf * nwg + blockIdx.x) * kTailHistRow + tv, pk);
+            }
+        }
         if (t == 0) {
             misc[0] = 0u;   // next iteration's failure count
             misc[5] = 0u;
             misc[9] = 0u;
             misc[2] = __float_as_uint(INFINITY);
         }
-        TAIL_STAMP(3);   // band records, component sums, publish
+        TAIL_STAMP(3);
         // ================= exchange =================
-        if (!exchange()) {
+        if (!exchange(set)) {
             exit_reason = 4;
             if (t == 0) __hip_atomic_fetch_add(&sync[kTailErrWord], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
         }
         TAIL_STAMP(5);   // arrive + wait for every workgroup
         // ================= phase C (every workgroup, identical arithmetic): reduce, verify, select, add, solve, update =====
-        reduce_rows(buf, false);
-        TAIL_STAMP(6);   // row sums
         uint32_t sel_bin = 0;   // coarse bin the band has shrunk to (wide bands)
         bool stall = false;
+        unsigned rset = set;    // accumulator set / record counter holding this iteration's records
+        // narrow bands: the record count and, speculatively, one record per thread travel with the sums (one hop)
+        unsigned long long rv[6] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+        unsigned n_band_raw = 0;
+        auto load_records_spec = [&]() {
+            n_band_raw = tail_ld_u32(&sync[kTailBandCntWord + 16 * rset]);
+            const float* rec = band_g + ((size_t)buf * kTailBandCap + (unsigned)tv) * kTailRec;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) rv[k] = tail_ld_u64(rec + 2 * k);
+        };
+        if (!wide) load_records_spec();
+        reduce_sums(set, false);
+        TAIL_STAMP(6);   // sums
         if (trim && wide && (uint32_t)llround(tot[29]) != 0u) {
             // ---- coarse counts of all workgroups -> hist[0..255]; thread t sums word t & 63 (4 bins) of rows t >> 6, + 8, ...
             {
-                const unsigned* wbase = reinterpret_cast<const unsigned*>(rows_g + (size_t)buf * nwg * kTailRow + 34) + (tv & 63);
+                const unsigned* wbase = reinterpret_cast<const unsigned*>(hist_g + (size_t)buf * nwg * kTailHistRow) + (tv & 63);
                 constexpr int kG = kTailThreads / 64, kL = 256 / kG;
                 unsigned wv2[kL];
 #pragma unroll
                 for (int u = 0; u < kL; ++u) {
                     const int b2 = (tv >> 6) + kG * u;
-                    wv2[u] = b2 < nwg ? tail_ld_u32(wbase + (size_t)b2 * (kTailRow * 2)) : 0u;
+                    wv2[u] = b2 < nwg ? tail_ld_u32(wbase + (size_t)b2 * (kTailHistRow * 2)) : 0u;
                 }
                 unsigned c4[4] = {0, 0, 0, 0};
                 bool sat = false;
@@ -732,7 +696,7 @@ k_tail(const float4* __restrict__ src, const float4* __restrict__ src_nrm, IterS
                     if (lane >= o) incl += v;
                 }
                 if (lane == 63) wtot[wave] = incl;
-                off[t] = incl - hv2;   // (off[] as scratch; the second reduce_rows rewrites it)
+                off[t] = incl - hv2;
             }
             __syncthreads();
             if (t < 256) {
@@ -755,44 +719,40 @@ k_tail(const float4* __restrict__ src, const float4* __restrict__ src_nrm, IterS
             __syncthreads();
             if (!stall) {
                 sel_bin = misc[10];
-                // ---- second exchange: band points below the bin become certain (delta row), those inside it the records
+                // ---- second exchange: band points below the bin become certain (delta sums), those inside it the records
                 buf = (int)(epoch & 1u);
+                rset = epoch & (kTailRing - 1);
+                double v[kSums];
+#pragma unroll
+                for (int k = 0; k < kSums; ++k) v[k] = 0.0;
                 bool mine[kTailPts];
+                unsigned slot[kTailPts];
 #pragma unroll
                 for (int u = 0; u < kTailPts; ++u) {
-                    const int sl = t + u * kTailThreads;
-                    float row[12];
-#pragma unroll
-                    for (int k = 0; k < 12; ++k) row[k] = 0.f;
                     mine[u] = false;
                     if (clsv[u] == 1) {
                         const uint32_t cb = coarse_bin(md2v[u]);
                         mine[u] = cb == sel_bin;
                         if (cb < sel_bin) {
-                            row[11] = 1.f;   // below the (shrunken) band
-                            if (wv[u] != 0.f) {
-#pragma unroll
-                                for (int k = 0; k < 7; ++k) row[k] = rF[u][k];
-                                row[7] = 1.f;
-                                row[8] = 1.f;
-                                row[10] = md2v[u];
-                            }
+                            v[31] += 1.0;   // below the (shrunken) band
+                            if (wv[u] != 0.f) accumulate(v, rF[u], md2v[u]);
                         }
                     }
-#pragma unroll
-                    for (int k = 0; k < 12; ++k) E[sl * kCohRow + k] = row[k];
                 }
-                my_records = publish_records(buf, mine, rF, md2v, wv);
-                publish_sums(buf, my_records);
-                if (!exchange()) {
+                reserve_records(rset, mine, slot);
+                publish_sums(v);
+#pragma unroll
+                for (int u = 0; u < kTailPts; ++u)
+                    if (mine[u]) store_record(buf, slot[u], rF[u], md2v[u], wv[u]);
+                if (!exchange(rset)) {
                     exit_reason = 4;
                     if (t == 0) __hip_atomic_fetch_add(&sync[kTailErrWord], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }
-                reduce_rows(buf, true);
+                load_records_spec();
+                reduce_sums(rset, true);
             }
         }
-        const unsigned n_band_raw = off[256];
         const bool band_bad = misc[5] != 0u || n_band_raw > (unsigned)kTailBandCap;
         const unsigned n_band = (trim && !band_bad && !stall) ? n_band_raw : 0u;
         if (trim) {
@@ -804,10 +764,11 @@ k_tail(const float4* __restrict__ src, const float4* __restrict__ src_nrm, IterS
                 break;
             }
             if (n_finite != 0) {
-                // ---- stage the band in LDS (factor rows, stride kCohRow), record i = j-th record of workgroup b in index order;
-                //      one-level select: an order-preserving key spreads the band's values (inside [band_lo, band_hi), or inside
-                //      coarse bin sel_bin of it) over kTailBins bins -- about one value per bin; the bin holding the rank is
-                //      resolved by direct ranking
+                // ---- the band's records stay in registers (record t came with the sums, records beyond the first kTailThreads take
+                //      a second batch); only their d2 keys go through LDS.  One-level select: an order-preserving key spreads the
+                //      band's values (inside [band_lo, band_hi), or inside coarse bin sel_bin of it) over kTailBins bins -- about
+                //      one value per bin; the bin holding the rank is resolved by direct ranking
+                unsigned long long rv2[6] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
                 uint32_t my_bin[kTailPts], my_u[kTailPts];
 #pragma unroll
                 for (int u = 0; u < kTailPts; ++u) {
@@ -815,28 +776,19 @@ k_tail(const float4* __restrict__ src, const float4* __restrict__ src_nrm, IterS
                     my_bin[u] = 0xffffffffu;
                     my_u[u] = 0u;
                     if (i < n_band) {
-                        int b2 = 0;
+                        if (u > 0) {
+                            const float* rec = band_g + ((size_t)buf * kTailBandCap + i) * kTailRec;
 #pragma unroll
-                        for (int step = 128; step >= 1; step >>= 1)
-                            if (off[b2 + step] <= i) b2 += step;
-                        const unsigned j = i - off[b2];
-                        const float* rec = band_g + (((size_t)buf * nwg + b2) * kTailWgBand + j) * kTailRec;
-                        unsigned long long v[6];
-#pragma unroll
-                        for (int k = 0; k < 6; ++k) v[k] = tail_ld_u64(rec + 2 * k);
-#pragma unroll
-                        for (int k = 0; k < 6; ++k) {
-                            bt[i * kCohRow + 2 * k] = __uint_as_float((unsigned)v[k]);
-                            bt[i * kCohRow + 2 * k + 1] = __uint_as_float((unsigned)(v[k] >> 32));
+                            for (int k = 0; k < 6; ++k) rv2[k] = tail_ld_u64(rec + 2 * k);
                         }
-                        my_u[u] = (unsigned)(v[3] >> 32);   // component 7: d2
+                        my_u[u] = (unsigned)((u == 0 ? rv[3] : rv2[3]) >> 32);   // component 7: d2
                         const double fpos = (double)(my_u[u] - u_lo) * f_scale - (double)sel_bin;   // in [0, 1) up to rounding
                         my_bin[u] = fpos > 0.0 ? min((uint32_t)(fpos * (double)kTailBins), (uint32_t)(kTailBins - 1)) : 0u;
                         atomicAdd(&hist[my_bin[u]], 1u);
                     }
                 }
                 __syncthreads();
-                TAIL_STAMP(7);   // band: staging
+                TAIL_STAMP(7);   // band: keys
                 {
                     // exclusive scan of the kTailBins counts, kBpt adjacent bins per thread
                     constexpr int kBpt = kTailBins / kTailThreads;
@@ -882,16 +834,32 @@ k_tail(const float4* __restrict__ src, const float4* __restrict__ src_nrm, IterS
                 __syncthreads();
                 TAIL_STAMP(9);   // band: members + rank
                 const float limit = __uint_as_float(misc[2]);
-                // ---- add the band records that survive the trim (index order: deterministic, the same on every workgroup)
-                double acc = tail_component_sum<true>(bt, part, (int)n_band, kParts, comp, limit);
-                acc += __shfl_xor(acc, 32);
-                if (lane < kSums) sh[wave][lane] = acc;
+                // ---- add the band records that survive the trim: each thread its own (list order x butterfly: the same sum on
+                //      every workgroup), straight from the registers the records arrived in
+                double v[kSums];
+#pragma unroll
+                for (int k = 0; k < kSums; ++k) v[k] = 0.0;
+#pragma unroll
+                for (int u = 0; u < kTailPts; ++u) {
+                    const unsigned i = (unsigned)(t + u * kTailThreads);
+                    const unsigned long long* r6 = u == 0 ? rv : rv2;
+                    const float d2r = __uint_as_float((unsigned)(r6[3] >> 32)), keptr = __uint_as_float((unsigned)r6[4]);
+                    if (i < n_band && d2r <= limit && keptr != 0.f) {
+                        const float F[7] = {__uint_as_float((unsigned)r6[0]), __uint_as_float((unsigned)(r6[0] >> 32)),
+                                            __uint_as_float((unsigned)r6[1]), __uint_as_float((unsigned)(r6[1] >> 32)),
+                                            __uint_as_float((unsigned)r6[2]), __uint_as_float((unsigned)(r6[2] >> 32)),
+                                            __uint_as_float((unsigned)r6[3])};
+                        accumulate(v, F, d2r);
+                    }
+                }
+                wave_reduce32(v);
+                if ((lane & 1) == 0) sh[wave][lane >> 1] = v[0];
                 __syncthreads();
                 if (t < kSums) {
-                    double v = 0.0;
+                    double v2 = 0.0;
 #pragma unroll
-                    for (int w2 = 0; w2 < kWaves; ++w2) v += sh[w2][t];
-                    tot[t] += v;
+                    for (int w2 = 0; w2 < kWaves; ++w2) v2 += sh[w2][t];
+                    tot[t] += v2;
                 }
                 __syncthreads();
             }
