@@ -125,8 +125,19 @@ k_reduce_update(const double* __restrict__ partials, int n_blocks, IterState* it
     if (threadIdx.x < kStateWords) s_state[threadIdx.x] = reinterpret_cast<const uint32_t*>(it)[threadIdx.x];
     double t = 0;
     if (!gathered && !finish) {
+        // (eight loads in flight per thread: one after the other, the ~25 rows a part sums at C3 were a chain of 25 L2 / Infinity
+        //  Cache round trips -- most of this kernel's 15 us on the select-based path)
         const int n_rows = fused ? kAccRows : n_blocks;
-        for (int b = part; b < n_rows; b += 32) t += partials[(size_t)b * kSums + comp];
+        for (int b0 = part; b0 < n_rows; b0 += 32 * 8) {
+            double v8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int b = b0 + 32 * u;
+                v8[u] = partials[(size_t)(b < n_rows ? b : part) * kSums + comp];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t += (b0 + 32 * u < n_rows) ? v8[u] : 0.0;
+        }
     }
     // Single-GPU fused path: the first kSpec * 32 band records (the usual band holds fewer) are loaded speculatively in
     // the same batch as the state -- their addresses do not depend on the record count, only their validity does; this
