@@ -4,7 +4,17 @@ import csv, glob, os, sys, collections
 root = sys.argv[1]
 want = sys.argv[2:] or ["k_match_g8", "k_tail"]
 tab = collections.defaultdict(dict)   # (kernel, dispatch order index) -> counter -> value
-for f in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
+def newest(pattern):
+    # gpurun merges every run's files next to the older ones: one file per pass directory, the most recent
+    by_dir = {}
+    for f in glob.glob(pattern, recursive=True):
+        d = os.path.relpath(f, root).split(os.sep)[0]
+        if d not in by_dir or os.path.getmtime(f) > os.path.getmtime(by_dir[d]):
+            by_dir[d] = f
+    return sorted(by_dir.values())
+
+
+for f in newest(os.path.join(root, "**", "*counter_collection.csv")):
     per = collections.defaultdict(float)
     names = {}
     for row in csv.DictReader(open(f)):
@@ -22,7 +32,7 @@ for f in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), r
                 if dd == d:
                     tab[(w, k)][c] = v
 dur = collections.defaultdict(list)
-for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
+for f in newest(os.path.join(root, "trace", "**", "*kernel_trace.csv")):
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
     for r in rows:
         for w in want:
