@@ -547,9 +547,9 @@ def main():
                         th.join()
                     rates.append(args.streams * per * ITERS / tb)
                 rates.sort()
-                # every stream's pose against the single-stream registration of the same clouds (T2): one of the streams at a time
-                # runs its tail in the persistent kernel, the others on the three-launch iteration -- same ids, sums equal up to
-                # the fp64 summation order
+                # every stream's pose against the single-stream registration of the same clouds (T2): a registration that is not
+                # alone on the device runs the three-launch iteration instead of the persistent tail -- same ids, sums equal up
+                # to the fp64 summation order
                 dmax = max(float(np.abs(np.asarray(Ti) - np.asarray(T2)).max()) for Ti in lastT)
                 assert dmax <= 2e-6, f"batched registrations disagree with the single-stream pose by {dmax}"
                 extras["batched"] = {"streams": args.streams, "registrations": args.streams * per, "workload": "c2",

@@ -353,6 +353,22 @@ static reg_status enqueue_fused(reg_handle* h, bool want_w) {
 // Across processes every grid barrier of the kernel is bounded (TailCfg::timeout_ticks) and ends in REG_DEVICE_ERROR.
 constexpr int kTailMaxDevices = 64;
 static std::mutex g_tail_mutex[kTailMaxDevices];
+// Registrations of this process currently inside reg_register, per device.  The persistent kernel takes every CU for the
+// whole tail (512 threads x 256 VGPRs + 117 KB of LDS per CU: nothing else is resident beside it), which is what ONE
+// registration wants and what a batch of concurrent ones does not: 64 C2 registrations on 8 streams run 57 k iterations/s
+// on the three-launch iteration and 50 k when one of them at a time holds the chip (bench.py --mode replicas, round 3).
+// So the tail is only taken when no other registration is in flight on the device.
+static std::atomic<int> g_reg_active[kTailMaxDevices];
+struct RegActiveGuard {
+    int dev;
+    explicit RegActiveGuard(int d) : dev(d >= 0 && d < kTailMaxDevices ? d : -1) {
+        if (dev >= 0) g_reg_active[dev].fetch_add(1, std::memory_order_relaxed);
+    }
+    ~RegActiveGuard() {
+        if (dev >= 0) g_reg_active[dev].fetch_sub(1, std::memory_order_relaxed);
+    }
+    bool alone() const { return dev >= 0 && g_reg_active[dev].load(std::memory_order_relaxed) == 1; }
+};
 static int g_tail_cus[kTailMaxDevices];          // 0: not probed yet, < 0: the kernel cannot be co-resident on this device
 static std::mutex g_tail_probe_mutex;
 
@@ -628,8 +644,9 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
     // The persistent tail (kernels_tail.hpp) replaces the burst of three-launch fused iterations when this registration
     // holds the device's tail lock (one persistent kernel per device at a time: see g_tail_mutex).
     const TailPlan tail_pl = (can_fuse && tail_eligible(h)) ? tail_plan(h) : TailPlan();
+    const RegActiveGuard active(h->prm.device);
     std::unique_lock<std::mutex> tail_lock;
-    if (tail_pl.ok) {
+    if (tail_pl.ok && (active.alone() || h->env.tail_always)) {
         tail_lock = std::unique_lock<std::mutex>(g_tail_mutex[h->prm.device], std::try_to_lock);
     }
     const bool use_tail = tail_pl.ok && tail_lock.owns_lock();

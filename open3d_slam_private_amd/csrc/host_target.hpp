@@ -41,6 +41,7 @@ struct EnvSwitches {
     bool hints = false;         // O3D_HINTS: histogram of the terminating search level of the last iteration
     bool stamps = false;        // O3D_STAMPS: in-kernel cycle stamps of the update kernel
     bool coh_stats = false;     // O3D_COH_STATS: share of the reading points the coherent fused kernel had to search
+    bool tail_always = false;   // O3D_TAIL_ALWAYS: take the persistent tail even while other registrations are in flight on the device (A/B)
     bool no_tail = false;       // O3D_NO_TAIL: three-launch fused iterations instead of the persistent tail kernel (A/B, escape hatch)
     int tail_wpc = 0;           // O3D_TAIL_WPC: cap on the tail kernel's workgroups per XCD class (0: CUs / 8)
     double dist_timeout_s = 30.0; // O3D_DIST_TIMEOUT_S: deadline of every wait of the distributed path
@@ -65,6 +66,7 @@ struct EnvSwitches {
         hints = getenv("O3D_HINTS") != nullptr;
         stamps = getenv("O3D_STAMPS") != nullptr;
         coh_stats = getenv("O3D_COH_STATS") != nullptr;
+        tail_always = getenv("O3D_TAIL_ALWAYS") != nullptr;
         no_tail = getenv("O3D_NO_TAIL") != nullptr;
         if (const char* v = getenv("O3D_TAIL_WPC")) tail_wpc = std::max(0, atoi(v));
         if (const char* v = getenv("O3D_DIST_TIMEOUT_S")) dist_timeout_s = std::max(0.5, atof(v));

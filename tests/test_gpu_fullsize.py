@@ -221,48 +221,66 @@ def test_c2_full_size_gicp_registration_vs_oracle():
     assert agree > 0.995, agree
 
 
-def test_c5_eight_full_size_c2_registrations_in_parallel_threads():
+def test_c5_eight_full_size_c2_registrations_in_parallel_threads(monkeypatch):
     """BASELINE configs[4] on ONE GPU: 8 independent handles, each with its own stream, registering 8 different full-size C2
-    problems (seed + i) at the same time from 8 host threads -- one of them at a time owns the device's persistent-tail
-    lock, the others take the three-launch iteration.  Every pose within 1e-4 m / 1e-4 rad of the oracle's for ITS problem."""
+    problems (seed + i) at the same time from 8 host threads.  Every pose within 1e-4 m / 1e-4 rad of the oracle's for ITS
+    problem.  Twice: with the default policy (a registration takes the persistent tail kernel only when it is alone on the
+    device, so the batch runs on the three-launch iteration) and with O3D_TAIL_ALWAYS (one registration at a time holds the
+    device's tail lock, the others fall back: the lock changes hands between rounds)."""
     import threading
     n_src, n_tgt, K = 100_000, 1_000_000, 8
     scenes = [synth.make_scene(n_src, n_tgt, seed=4321 + i) for i in range(K)]
-    regs = []
-    for sc in scenes:
-        p = capi.shipped_params()
-        p.use_xicp = 0
-        p.fixed_iters = ITERS
-        r = capi.Registration(p)
-        r.set_target(sc.tgt_xyz, sc.tgt_nrm)
-        r.set_source(sc.src_xyz, sc.src_nrm)
-        regs.append(r)
-    out = [None] * K
-    errs = []
-    start = threading.Barrier(K)
+    oracle_T = [orc.icp_p2pl(sc.tgt_xyz, sc.tgt_nrm, sc.src_xyz, sc.src_nrm, max_dist=0.5, trim_ratio=0.9, max_normal_angle=1.57,
+                             fixed_iters=ITERS, n_threads=NT)[0] for sc in scenes]
+    for always in (False, True):
+        if always:
+            monkeypatch.setenv("O3D_TAIL_ALWAYS", "1")     # read when the handle is created
+        regs = []
+        for sc in scenes:
+            p = capi.shipped_params()
+            p.use_xicp = 0
+            p.fixed_iters = ITERS
+            r = capi.Registration(p)
+            r.set_target(sc.tgt_xyz, sc.tgt_nrm)
+            r.set_source(sc.src_xyz, sc.src_nrm)
+            regs.append(r)
+        out = [None] * K
+        errs = []
+        start = threading.Barrier(K)
 
-    def work(i):
-        try:
-            start.wait()
-            for _ in range(3):   # several rounds: the lock changes hands
-                out[i] = regs[i].register(np.eye(4))
-        except Exception as e:   # noqa: BLE001
-            errs.append((i, repr(e)))
+        def work(i):
+            try:
+                start.wait()
+                for _ in range(3):   # several rounds: the lock changes hands
+                    out[i] = regs[i].register(np.eye(4))
+            except Exception as e:   # noqa: BLE001
+                errs.append((i, repr(e)))
 
-    ths = [threading.Thread(target=work, args=(i,)) for i in range(K)]
-    for t in ths:
-        t.start()
-    for t in ths:
-        t.join()
-    assert not errs, errs
-    n_tail = 0
-    for i, sc in enumerate(scenes):
-        T, res = out[i]
-        assert res.iterations == ITERS
-        n_tail += int(res.n_tail_launches > 0)
-        To, ores = orc.icp_p2pl(sc.tgt_xyz, sc.tgt_nrm, sc.src_xyz, sc.src_nrm, max_dist=0.5, trim_ratio=0.9,
-                                max_normal_angle=1.57, fixed_iters=ITERS, n_threads=NT)
-        dt, dr = synth.pose_error(T, To)
-        assert dt <= 1e-4 and dr <= 1e-4, (i, dt, dr)
-        regs[i].close()
-    assert n_tail >= 1
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(K)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        assert not errs, errs
+        n_tail = 0
+        for i in range(K):
+            T, res = out[i]
+            assert res.iterations == ITERS
+            n_tail += int(res.n_tail_launches > 0)
+            dt, dr = synth.pose_error(T, oracle_T[i])
+            assert dt <= 1e-4 and dr <= 1e-4, (always, i, dt, dr)
+            regs[i].close()
+        if always:
+            assert n_tail >= 1
+    # alone on the device, the same handle does take the tail
+    p = capi.shipped_params()
+    p.use_xicp = 0
+    p.fixed_iters = ITERS
+    r = capi.Registration(p)
+    r.set_target(scenes[0].tgt_xyz, scenes[0].tgt_nrm)
+    r.set_source(scenes[0].src_xyz, scenes[0].src_nrm)
+    T, res = r.register(np.eye(4))
+    assert res.n_tail_launches >= 1
+    dt, dr = synth.pose_error(T, oracle_T[0])
+    assert dt <= 1e-4 and dr <= 1e-4
+    r.close()
