@@ -116,7 +116,7 @@ EXPORTS = ["reg_default_params", "reg_shipped_params", "reg_create", "reg_destro
            "reg_information_matrix", "reg_set_source_f64", "reg_debug_configure",
            "reg_dist_get_unique_id", "reg_dist_init", "reg_dist_init_custom", "reg_dist_register", "reg_dist_shutdown",
            "reg_dist_info", "reg_dist_steer_create", "reg_dist_steer_destroy", "reg_dist_steer_step",
-           "reg_dist_steer_counts"]
+           "reg_dist_steer_counts", "reg_host_tail_plan"]
 
 
 def lib_path() -> str:
@@ -706,3 +706,14 @@ def host_centroid(xyz):
     out = np.zeros(3, np.float32)
     load_library().reg_host_centroid(_ptr(xyz), xyz.shape[1], xyz.shape[0], _ptr(out))
     return out
+
+
+def host_tail_plan(n, cus=256):
+    """Launch plan of the persistent tail kernel for an n-point reading: (usable, workgroups, workgroups per XCD class, reading
+    points per XCD class) -- host-only (reg_host_tail_plan)."""
+    lib = load_library()
+    lib.reg_host_tail_plan.argtypes = [C.c_int64, C.c_int32, C.POINTER(C.c_int32)]
+    lib.reg_host_tail_plan.restype = None
+    out = (C.c_int32 * 4)()
+    lib.reg_host_tail_plan(int(n), int(cus), out)
+    return bool(out[0]), int(out[1]), int(out[2]), int(out[3])

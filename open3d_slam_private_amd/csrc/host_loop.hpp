@@ -393,13 +393,11 @@ static int tail_device_cus(int dev) {
     return g_tail_cus[dev];
 }
 
-static TailPlan tail_plan(const reg_handle* h) {
+static TailPlan tail_plan_for(int64_t n, int cus, int wpc_cap) {
     TailPlan pl;
-    const int cus = tail_device_cus(h->prm.device);
-    if (cus < 8 || h->n <= 0) return pl;
+    if (cus < 8 || n <= 0) return pl;
     int wpc_max = cus / 8;
-    if (h->env.tail_wpc > 0) wpc_max = std::min(wpc_max, h->env.tail_wpc);
-    const int64_t n = h->n;
+    if (wpc_cap > 0) wpc_max = std::min(wpc_max, wpc_cap);
     pl.wpc = (int)std::max<int64_t>(1, std::min<int64_t>(wpc_max, (n + 2047) / 2048));
     pl.chunk8 = (int)((((n + 7) / 8) + 7) / 8 * 8);
     const int64_t octets = pl.chunk8 / 8, per_wg = (octets + pl.wpc - 1) / pl.wpc * 8;
@@ -407,6 +405,7 @@ static TailPlan tail_plan(const reg_handle* h) {
     pl.ok = per_wg <= kTailSlots;
     return pl;
 }
+static TailPlan tail_plan(const reg_handle* h) { return tail_plan_for(h->n, tail_device_cus(h->prm.device), h->env.tail_wpc); }
 
 static bool tail_eligible(const reg_handle* h) {
     return h->prm.cost == REG_COST_P2PL && h->dbg.disable_fused != 1 && !(h->dbg.debug_flags & (16 | 64 | 128)) &&
@@ -553,6 +552,14 @@ static void fill_result(reg_handle* h, const double* sums, reg_result* res) {
 }
 
 extern "C" {
+
+void reg_host_tail_plan(int64_t n, int32_t cus, int32_t plan[4]) {
+    const TailPlan pl = tail_plan_for(n, cus, 0);
+    plan[0] = pl.ok ? 1 : 0;
+    plan[1] = pl.grid;
+    plan[2] = pl.wpc;
+    plan[3] = pl.chunk8;
+}
 
 reg_status reg_prepare(reg_handle* h, const float T_init[16]) {
     if (!h || !T_init) return REG_BAD_ARGUMENT;

@@ -257,3 +257,27 @@ transformationCheckers:
     d = capi.shipped_params()
     assert d.use_xicp == 1 and d.xicp_enough == 250 and d.xicp_strong_angle_deg == 45   # the shipped chain has it on
     assert capi.default_params().use_xicp == 0                                           # setDefault() does not
+
+
+def test_tail_kernel_slot_mapping_covers_every_reading_point_exactly_once():
+    """The persistent tail kernel (csrc/kernels_tail.hpp) deals reading points to workgroup slots in octets, round-robin inside an
+    XCD class (blockIdx % 8 keeps one contiguous eighth of the reading).  The plan the host computes and the mapping the kernel
+    evaluates -- restated here from the header's formula -- must put every point 0 .. n-1 into exactly one (workgroup, slot)."""
+    for n, cus in ((1, 256), (37, 256), (4000, 256), (70001, 256), (100_000, 256), (200_000, 256), (262_144, 256), (50_000, 64),
+                   (262_145, 256), (0, 256), (1000, 4)):
+        ok, grid, wpc, chunk8 = capi.host_tail_plan(n, cus)
+        if n <= 0 or cus < 8:
+            assert not ok
+            continue
+        assert grid == 8 * wpc and grid <= cus and chunk8 % 8 == 0 and 8 * chunk8 >= n
+        if n > 1024 * grid:
+            assert not ok
+            continue
+        assert ok, (n, cus)
+        b = np.arange(grid)[:, None]
+        s = np.arange(1024)[None, :]
+        r_in = (((s >> 3) * wpc + (b >> 3)) << 3) + (s & 7)
+        q = (b & 7) * chunk8 + r_in
+        valid = (r_in < chunk8) & (q < n)
+        hit = np.bincount(q[valid].ravel(), minlength=n)
+        assert hit.shape[0] == n and (hit == 1).all(), (n, cus)
