@@ -384,11 +384,16 @@ static int tail_device_cus(int dev) {
     if (g_tail_cus[dev] != 0) return g_tail_cus[dev];
     int cus = 0, nb = 0;
     hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int nb2 = 0;
     if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tail), hipFuncAttributeMaxDynamicSharedMemorySize, kTailLdsBytes);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tail<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kTailLdsBytes);
     if (e == hipSuccess)
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k_tail), kTailThreads, kTailLdsBytes);
-    g_tail_cus[dev] = (e == hipSuccess && nb >= 1 && cus >= 8) ? cus : -1;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tail<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kTailLdsBytes);
+    if (e == hipSuccess)
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k_tail<false>), kTailThreads, kTailLdsBytes);
+    if (e == hipSuccess)
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb2, reinterpret_cast<const void*>(k_tail<true>), kTailThreads, kTailLdsBytes);
+    g_tail_cus[dev] = (e == hipSuccess && nb >= 1 && nb2 >= 1 && cus >= 8) ? cus : -1;
     (void)hipGetLastError();
     return g_tail_cus[dev];
 }
@@ -408,8 +413,9 @@ static TailPlan tail_plan_for(int64_t n, int cus, int wpc_cap) {
 static TailPlan tail_plan(const reg_handle* h) { return tail_plan_for(h->n, tail_device_cus(h->prm.device), h->env.tail_wpc); }
 
 static bool tail_eligible(const reg_handle* h) {
-    return h->prm.cost == REG_COST_P2PL && h->dbg.disable_fused != 1 && !(h->dbg.debug_flags & (16 | 64 | 128)) &&
-           h->dbg.lanes_per_point != 4 && !h->env.no_tail && tail_plan(h).ok;
+    if (h->prm.cost != REG_COST_P2PL && h->env.no_gicp_tail) return false;
+    return h->dbg.disable_fused != 1 && !(h->dbg.debug_flags & (16 | 64 | 128)) && h->dbg.lanes_per_point != 4 && !h->env.no_tail &&
+           tail_plan(h).ok;
 }
 
 // Enqueue the tail for at most `max_iters` iterations; the kernel reports ONCE (sequence h->seq) when it leaves.
@@ -431,12 +437,20 @@ static reg_status enqueue_tail(reg_handle* h, const TailPlan& pl, int max_iters,
     uint8_t* hint = h->dbg.match_variant == 2 ? nullptr : h->i_hint.as<uint8_t>();
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool timed = h->profiling && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+    const bool gicp = h->prm.cost != REG_COST_P2PL;
     auto args = [&](auto launch) {
-        launch(k_tail, dim3(pl.grid), dim3(kTailThreads), (const float4*)h->s_xyz.as<float4>(),
-               (const float4*)(h->has_snrm ? h->s_nrm.as<float4>() : nullptr), h->i_iter.as<IterState>(), h->grid,
-               (const float4*)h->t_nrm.as<float4>(), f, h->i_pos.as<int>(), h->i_d2.as<float>(), w, hint,
-               (const float4*)h->i_cache.as<float4>(), h->i_tail_sync.as<unsigned>(), h->i_tail_rows.as<double>(),
-               h->i_tail_band.as<float>(), h->d_mirror, cfg);
+        // GICP: the covariances of the reading / the reference travel in the two attribute arguments
+        const float4* s_attr = gicp ? (const float4*)h->s_cov.as<float4>() : (const float4*)(h->has_snrm ? h->s_nrm.as<float4>() : nullptr);
+        const float4* t_attr = gicp ? (const float4*)h->t_cov.as<float4>() : (const float4*)h->t_nrm.as<float4>();
+        auto go = [&](auto kernel) {
+            launch(kernel, dim3(pl.grid), dim3(kTailThreads), (const float4*)h->s_xyz.as<float4>(), s_attr, h->i_iter.as<IterState>(),
+                   h->grid, t_attr, f, h->i_pos.as<int>(), h->i_d2.as<float>(), w, hint, (const float4*)h->i_cache.as<float4>(),
+                   h->i_tail_sync.as<unsigned>(), h->i_tail_rows.as<double>(), h->i_tail_band.as<float>(), h->d_mirror, cfg);
+        };
+        if (gicp)
+            go(k_tail<true>);
+        else
+            go(k_tail<false>);
     };
     if (timed) {
         args([&](auto k, dim3 g, dim3 b, auto... a) { hipExtLaunchKernelGGL(k, g, b, kTailLdsBytes, h->stream, e0, e1, 0, a...); });
@@ -638,7 +652,7 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
     // device stalls the queue and the host repairs that iteration on the generic path.
     const bool can_fuse = p2pl && h->dbg.disable_fused != 1;
     const bool trimming = p2pl && h->prm.use_trimmed && h->prm.trim_ratio != 1.0f;
-    const int kGenericFirst = trimming ? 2 : 1;
+    const int kGenericFirst = trimming ? 2 : (p2pl ? 1 : std::max(1, h->env.gicp_tail_after));
     const int kAhead = h->env.lookahead;
     const HostMirror* mir = h->h_mirror;
     int generic_left = kGenericFirst;
@@ -650,7 +664,8 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
     int stalls = 0;
     // The persistent tail (kernels_tail.hpp) replaces the burst of three-launch fused iterations when this registration
     // holds the device's tail lock (one persistent kernel per device at a time: see g_tail_mutex).
-    const TailPlan tail_pl = (can_fuse && tail_eligible(h)) ? tail_plan(h) : TailPlan();
+    // (GICP has no three-launch fused form: without the tail lock its iterations stay select-based)
+    const TailPlan tail_pl = ((can_fuse || !p2pl) && tail_eligible(h)) ? tail_plan(h) : TailPlan();
     const RegActiveGuard active(h->prm.device);
     std::unique_lock<std::mutex> tail_lock;
     if (tail_pl.ok && (active.alone() || h->env.tail_always)) {
@@ -749,7 +764,7 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
                           std::fabs(mir->limit_last - mir->limit_prev) <= settle_tol * mir->limit_last;
             }
             const auto tq0 = std::chrono::steady_clock::now();
-            const bool go_generic = !can_fuse || generic_left > 0 || !settled;
+            const bool go_generic = !(can_fuse || use_tail) || generic_left > 0 || !settled;
             if (go_generic) {
                 s = enqueue_iteration(h, true);   // weights are always written: reg_get_correspondences reports them
                 if (generic_left > 0) --generic_left;

@@ -46,6 +46,8 @@ struct EnvSwitches {
     int tail_wpc = 0;           // O3D_TAIL_WPC: cap on the tail kernel's workgroups per XCD class (0: CUs / 8)
     double dist_timeout_s = 30.0; // O3D_DIST_TIMEOUT_S: deadline of every wait of the distributed path
     float tail_timeout_s = 2.f; // O3D_TAIL_TIMEOUT_S: bound of every grid barrier of the tail kernel
+    bool no_gicp_tail = false;    // O3D_NO_GICP_TAIL=1: GICP stays on its select-based iteration
+    int gicp_tail_after = 1;      // O3D_GICP_TAIL_AFTER: select-based GICP iterations before the tail kernel takes over
     float tail_settle_tol = 1.2f; // O3D_TAIL_SETTLE: relative change of the trimmed limit below which the tail kernel takes over
     int lookahead = 2;          // O3D_KAHEAD
     float settle_tol = 0.05f;   // O3D_SETTLE: relative change of the trimmed limit below which the fused iterations start (round 2 sweep:
@@ -71,6 +73,8 @@ struct EnvSwitches {
         if (const char* v = getenv("O3D_TAIL_WPC")) tail_wpc = std::max(0, atoi(v));
         if (const char* v = getenv("O3D_DIST_TIMEOUT_S")) dist_timeout_s = std::max(0.5, atof(v));
         if (const char* v = getenv("O3D_TAIL_SETTLE")) tail_settle_tol = (float)atof(v);
+        if (const char* v = getenv("O3D_NO_GICP_TAIL")) no_gicp_tail = atoi(v) != 0;
+        if (const char* v = getenv("O3D_GICP_TAIL_AFTER")) gicp_tail_after = atoi(v);
         if (const char* v = getenv("O3D_TAIL_TIMEOUT_S")) tail_timeout_s = std::min(30.f, std::max(0.01f, (float)atof(v)));
         if (const char* v = getenv("O3D_KAHEAD")) lookahead = std::max(1, atoi(v));
         if (const char* v = getenv("O3D_SETTLE")) settle_tol = (float)atof(v);

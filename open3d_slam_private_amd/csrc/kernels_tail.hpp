@@ -97,8 +97,8 @@ struct TailCfg {
 
 // LDS carve-up (dynamic region only; every offset a multiple of 16)
 struct TailLds {
-    static constexpr int kRows = 0;                                   // float4 [4][1024]
-    static constexpr int kUnion = kRows + 4 * kTailSlots * 16;        // segment lists of the searches | ranking keys of the select
+    static constexpr int kRows = 0;                                   // float4 [5][1024] (row 4: GICP only)
+    static constexpr int kUnion = kRows + 5 * kTailSlots * 16;        // segment lists of the searches | ranking keys of the select
     static constexpr int kUnionBytes = 36864;
     static constexpr int kD2 = kUnion + kUnionBytes;                  // float [1024]
     static constexpr int kFail = kD2 + kTailSlots * 4;              // uint16 [1024]
@@ -233,9 +233,200 @@ __device__ __noinline__ void tail_solve_update(IterState* sit, const double* tot
     if (!iterate) sit->done = 1;
 }
 
+// GICP factor of ONE pair, added into the 32 running sums (the arithmetic of k_linearize_gicp, kernels_match.hpp:
+// r = q - T p, M = (Cq + R Cp R^T)^-1, J = [R skew(p), -R]; H += J^T M J, b += J^T M r, e += 0.5 r^T M r; fp64 per pair).
+__device__ __forceinline__ void tail_gicp_factor(const Xf& T, const float4 s, const float4 a0, const float4 a1, const float4 q,
+                                                 const float4 b0, const float4 b1, float d2, double (&v)[kSums]) {
+    const float3 tp = xf_point(T, s.x, s.y, s.z);
+    const double r[3] = {(double)q.x - (double)tp.x, (double)q.y - (double)tp.y, (double)q.z - (double)tp.z};
+    const double Cp[9] = {a0.x, a0.y, a0.z, a0.y, a0.w, a1.x, a0.z, a1.x, a1.y};
+    const double Cq[9] = {b0.x, b0.y, b0.z, b0.y, b0.w, b1.x, b0.z, b1.x, b1.y};
+    double R[9];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) R[3 * a + c] = (double)T.m[4 * a + c];
+    double RC[9], S[9];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double t = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) t += R[3 * a + k] * Cp[3 * k + c];
+            RC[3 * a + c] = t;
+        }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double t = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) t += RC[3 * a + k] * R[3 * c + k];
+            S[3 * a + c] = t + Cq[3 * a + c];
+        }
+    double Mi[9];
+    {
+        const double a = S[0], b = S[1], c = S[2], d = S[4], e = S[5], ff = S[8];
+        const double co00 = d * ff - e * e, co01 = c * e - b * ff, co02 = b * e - c * d;
+        const double id = 1.0 / (a * co00 + b * co01 + c * co02);
+        Mi[0] = co00 * id;
+        Mi[1] = Mi[3] = co01 * id;
+        Mi[2] = Mi[6] = co02 * id;
+        Mi[4] = (a * ff - c * c) * id;
+        Mi[5] = Mi[7] = (b * c - a * e) * id;
+        Mi[8] = (a * d - b * b) * id;
+    }
+    const double px = s.x, py = s.y, pz = s.z;
+    const double sk[9] = {0, -pz, py, pz, 0, -px, -py, px, 0};
+    double J[18];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double t = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) t += R[3 * a + k] * sk[3 * k + c];
+            J[6 * a + c] = t;
+            J[6 * a + 3 + c] = -R[3 * a + c];
+        }
+    double MJ[18], Mr[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            double t = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) t += Mi[3 * a + k] * J[6 * k + c];
+            MJ[6 * a + c] = t;
+        }
+        Mr[a] = Mi[3 * a] * r[0] + Mi[3 * a + 1] * r[1] + Mi[3 * a + 2] * r[2];
+    }
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int c = a; c < 6; ++c) {
+            double t = 0;
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) t += J[6 * kk + a] * MJ[6 * kk + c];
+            v[k++] += t;
+        }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) v[21 + a] += J[a] * Mr[0] + J[6 + a] * Mr[1] + J[12 + a] * Mr[2];
+    v[27] += 0.5 * (r[0] * Mr[0] + r[1] * Mr[1] + r[2] * Mr[2]);
+    v[28] += 1.0;
+    v[29] += 1.0;
+    v[30] += (double)d2;
+}
+
+// R8 + R9 of the tail kernel for the GICP cost: the arithmetic of k_reduce_update's GICP branch (fp64 Gauss-Jordan, se(3)
+// exponential, right-multiplied update, the two stop rules), wave 0 of every workgroup.
+__device__ __noinline__ void tail_solve_update_gicp(IterState* sit, const double* tot, double* s_dl) {
+    const int lane = (int)(threadIdx.x & 63);
+    const int r = lane >> 3, c = lane & 7;
+    double a = 0.0;
+    if (r < 6 && c < 7) {
+        if (c < 6) {
+            const int lo = r < c ? r : c, hi = r < c ? c : r;
+            a = tot[lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo)];
+        } else {
+            a = -tot[21 + r];
+        }
+    }
+    const double a_orig = a;
+    double dmax = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) dmax = fmax(dmax, fabs(__shfl(a_orig, j * 8 + j)));
+    bool well = dmax > 0.0;
+    const double piv_thr = 1e-10 * dmax;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const double pj = __shfl(a, j * 8 + j);
+        well = well && (pj > piv_thr);
+        const double ajc = __shfl(a, j * 8 + c);
+        const double arj = __shfl(a, r * 8 + j);
+        const double qd = ajc / pj;
+        a = (r == j) ? qd : a - arj * qd;
+    }
+    double xsol[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) xsol[i] = __shfl(a, i * 8 + 6);
+    if (lane != 0) return;
+    const double cnt = tot[28];
+    sit->limit_prev = sit->limit_last;
+    sit->limit_last = INFINITY;
+    sit->band_lo = INFINITY;
+    sit->band_hi = INFINITY;
+    sit->band_count = 0;
+    sit->stall = 0;
+    float r_T[16];
+    for (int i = 0; i < 16; ++i) r_T[i] = sit->T[i];
+    if (cnt == 0.0) {
+        sit->status = REG_NO_CORRESPONDENCES;
+        sit->done = 1;
+        return;
+    }
+    const double fit = cnt / (double)sit->n_total, rmse = sqrt(tot[30] / cnt);
+    if (sit->gicp_stop_rule == 1 && sit->fixed_iters <= 0) {
+        const bool conv = sit->iterations >= 1 && fabs(fit - sit->fit_prev) < (double)sit->gicp_rel_fitness &&
+                          fabs(rmse - sit->rmse_prev) < (double)sit->gicp_rel_rmse;
+        if (conv || sit->iterations >= sit->max_iter) {   // Open3D ICPConvergenceCriteria: no further update (see k_reduce_update)
+            if (conv)
+                sit->chk.converged = true;
+            else
+                sit->chk.max_iter_reached = true;
+            for (int i = 0; i < 16; ++i) sit->T_prev[i] = r_T[i];
+            sit->done = 1;
+            return;
+        }
+    }
+    sit->fit_prev = fit;
+    sit->rmse_prev = rmse;
+    double dl[6], E[16], Tn[16];
+    int rank = 6;
+    if (well) {
+        for (int i = 0; i < 6; ++i) dl[i] = xsol[i];
+    } else {
+        rank = upd_solve_sym6(tot, s_dl);
+        for (int i = 0; i < 6; ++i) dl[i] = s_dl[i];
+    }
+    sit->rank_last = rank;
+    se3_exp(dl, E);
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double v = 0;
+            for (int kk = 0; kk < 4; ++kk) v += sit->Td[4 * i + kk] * E[4 * kk + j];
+            Tn[4 * i + j] = v;
+        }
+    for (int i = 0; i < 16; ++i) {
+        sit->T_prev[i] = r_T[i];
+        sit->Td[i] = Tn[i];
+        sit->T[i] = (float)Tn[i];
+    }
+    sit->iterations += 1;
+    if (sit->fixed_iters > 0) {
+        if (sit->iterations >= sit->fixed_iters) sit->done = 1;
+    } else if (sit->gicp_stop_rule == 1) {
+        // decided by the next evaluation (above)
+    } else {
+        const double dr = sqrt(dl[0] * dl[0] + dl[1] * dl[1] + dl[2] * dl[2]);
+        const double dt = sqrt(dl[3] * dl[3] + dl[4] * dl[4] + dl[5] * dl[5]);
+        if (dr < (double)sit->gicp_rot_eps && dt < (double)sit->gicp_trans_eps) {
+            sit->chk.converged = true;
+            sit->done = 1;
+        } else if (sit->iterations >= sit->max_iter) {
+            sit->chk.max_iter_reached = true;
+            sit->done = 1;
+        }
+    }
+}
+
+template <bool kGicp>
 __global__ void __launch_bounds__(kTailThreads)
-k_tail(const float4* __restrict__ src, const float4* __restrict__ src_nrm, IterState* __restrict__ it_g, Grid g,
-       const float4* __restrict__ tgt_nrm, FilterCfg f, int* __restrict__ pos_io, float* __restrict__ d2_out,
+k_tail(const float4* __restrict__ src, const float4* __restrict__ src_nrm /* GICP: the reading's covariances, 2 x float4 */,
+       IterState* __restrict__ it_g, Grid g, const float4* __restrict__ tgt_nrm /* GICP: the reference's covariances */,
+       FilterCfg f, int* __restrict__ pos_io, float* __restrict__ d2_out,
        float* __restrict__ w_out, uint8_t* __restrict__ hint_g, const float4* __restrict__ cache, unsigned* __restrict__ sync,
        double* __restrict__ hist_g /* [2][grid][kTailHistRow] */, float* __restrict__ band_g /* [2][kTailBandCap][12] */,
        HostMirror* host, TailCfg cfg) {
@@ -272,6 +463,7 @@ k_tail(const float4* __restrict__ src, const float4* __restrict__ src_nrm, IterS
     int64_t q[kTailPts];
     bool valid[kTailPts];
     float4 s[kTailPts], sn[kTailPts];   // the reading point and its normal: constant, in registers for the whole launch
+    float4 sc1[kTailPts];               // (GICP: sn = covariance xx xy xz yy, sc1 = yz zz)
 #pragma unroll
     for (int u = 0; u < kTailPts; ++u) {
         const int sl = t + u * kTailThreads;
@@ -289,12 +481,25 @@ k_tail(const float4* __restrict__ src, const float4* __restrict__ src_nrm, IterS
         const float4 r2 = cache[2 * (size_t)n + q[u]], r3 = cache[3 * (size_t)n + q[u]];
         const int pprev = pos_io[q[u]];
         s[u] = src[q[u]];
-        sn[u] = f.use_normal ? src_nrm[q[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+        sc1[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kGicp) {
+            // the select-based GICP iteration leaves no {matched point, covariance} rows in the cache: gathered once, here
+            sn[u] = src_nrm[2 * q[u]];
+            sc1[u] = src_nrm[2 * q[u] + 1];
+            const int pc = pprev >= 0 ? pprev : 0;
+            r1 = g.pts[pc];
+            float4 c0 = tgt_nrm[2 * (size_t)pc], c1 = tgt_nrm[2 * (size_t)pc + 1];
+            c1.w = (valid[u] && pprev >= 0) ? 1.f : 0.f;
+            st_rows[2 * kTailSlots + sl] = c0;
+            st_rows[4 * kTailSlots + sl] = c1;
+        } else {
+            sn[u] = f.use_normal ? src_nrm[q[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+            st_rows[2 * kTailSlots + sl] = r2;
+        }
         if (!valid[u]) r0.w = -1.f;
         r1.w = __int_as_float(valid[u] ? pprev : -1);
         st_rows[sl] = r0;
         st_rows[kTailSlots + sl] = r1;
-        st_rows[2 * kTailSlots + sl] = r2;
         st_rows[3 * kTailSlots + sl] = r3;
         hnt[sl] = hint_g ? hint_g[q[u]] : (uint8_t)0;
         d2s[sl] = INFINITY;
@@ -433,7 +638,7 @@ k_tail(const float4* __restrict__ src, const float4* __restrict__ src_nrm, IterS
 #pragma unroll
         for (int k = 0; k < 12; ++k) T.m[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sit->T[k])));   // uniform: SGPRs
         const float band_lo = sit->band_lo, band_hi = sit->band_hi;
-        const bool trim = sit->use_trim && sit->trim_ratio != 1.0f;
+        const bool trim = !kGicp && sit->use_trim && sit->trim_ratio != 1.0f;
         // A WIDE band (the trimmed limit still moves by per cents: first iterations after the large corrections) holds
         // thousands of points: too many to hand every workgroup as records.  Two exchanges then: first the certain sums and,
         // per workgroup, the counts of its band points in kTailCoarse coarse bins; every workgroup finds the coarse bin b*
@@ -455,7 +660,8 @@ k_tail(const float4* __restrict__ src, const float4* __restrict__ src_nrm, IterS
                          ru = st_rows[3 * kTailSlots + sl];
             const int pprev = __float_as_int(tq.w);
             bool pass = false;
-            if (valid[u] && c.w > 0.f && pprev >= 0 && nn.w == 1.f) {
+            const float attr_ok = kGicp ? st_rows[4 * kTailSlots + sl].w : nn.w;   // matched point + attribute rows are cached
+            if (valid[u] && c.w > 0.f && pprev >= 0 && attr_ok == 1.f) {
                 const float dx = p[u].x - tq.x, dy = p[u].y - tq.y, dz = p[u].z - tq.z;
                 float a = dx * dx;
                 float b2 = dy * dy;
@@ -508,9 +714,18 @@ k_tail(const float4* __restrict__ src, const float4* __restrict__ src_nrm, IterS
                     if (sub == 0) {
                         hnt[slot] = (uint8_t)(lvl + 1);
                         const int pc = bb.pos >= 0 ? bb.pos : 0;
-                        float4 tq = tgt_nrm[2 * (size_t)pc];       // {point, normal} pair: one line
-                        float4 nn = tgt_nrm[2 * (size_t)pc + 1];
-                        nn.w = 1.f;
+                        float4 tq, nn;
+                        if (kGicp) {
+                            tq = g.pts[pc];
+                            nn = tgt_nrm[2 * (size_t)pc];                 // covariance xx xy xz yy
+                            float4 c1 = tgt_nrm[2 * (size_t)pc + 1];     // yz zz
+                            c1.w = 1.f;
+                            st_rows[4 * kTailSlots + slot] = c1;
+                        } else {
+                            tq = tgt_nrm[2 * (size_t)pc];       // {point, normal} pair: one line
+                            nn = tgt_nrm[2 * (size_t)pc + 1];
+                            nn.w = 1.f;
+                        }
                         float4 ru = make_float4(INFINITY, INFINITY, INFINITY, 1.f);   // no runner-up seen: infinitely far
                         if (bb.pos2 >= 0) {
                             const float4 t2 = g.pts[bb.pos2];
@@ -555,7 +770,13 @@ k_tail(const float4* __restrict__ src, const float4* __restrict__ src_nrm, IterS
                 const float md2 = d2s[sl];
                 float w = 0.f;
                 int cls = 2;   // 0: certainly kept, 1: band, 2: dropped / unmatched
-                if (valid[u] && mpos >= 0) {
+                if (kGicp) {
+                    if (valid[u] && mpos >= 0) {
+                        w = 1.f;
+                        cls = 0;
+                        tail_gicp_factor(T, s[u], sn[u], sc1[u], tq, nn, st_rows[4 * kTailSlots + sl], md2, v);
+                    }
+                } else if (valid[u] && mpos >= 0) {
                     w = 1.f;
                     if (f.use_maxdist && !(md2 <= f.outlier_max_d2)) w = 0.f;
                     if (f.use_normal) {
@@ -866,7 +1087,12 @@ k_tail(const float4* __restrict__ src, const float4* __restrict__ src_nrm, IterS
         }
         TAIL_STAMP(10);   // band add
         if (t < kSums) sit->sums[t] = tot[t];
-        if (wave == 0) tail_solve_update(sit, tot, misc, s_x, trim, n_band_raw);
+        if (wave == 0) {
+            if (kGicp)
+                tail_solve_update_gicp(sit, tot, reinterpret_cast<double*>(s_x));
+            else
+                tail_solve_update(sit, tot, misc, s_x, trim, n_band_raw);
+        }
         __syncthreads();
         TAIL_STAMP(11);   // solve, pose update, checkers
         if (sit->done) {

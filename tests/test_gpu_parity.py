@@ -1159,3 +1159,46 @@ def test_persistent_tail_stall_and_repair_and_iteration_budget():
     T3, r3, *_ = _register(sc, fixed_iters=90, disable_fused=1)
     assert r2.iterations == r3.iterations == 90 and r2.n_tail_launches >= 2 and r2.n_tail_iterations >= 80
     assert np.abs(T2 - T3).max() <= 2e-6
+
+
+def _register_gicp(sc, max_dist=0.5, **over):
+    p = capi.default_params()
+    p.cost = capi.COST_GICP
+    p.use_trimmed = 0
+    p.max_dist = max_dist
+    for k, v in over.items():
+        setattr(p, k, v)
+    reg = capi.Registration(p)
+    reg.set_target(sc.tgt_xyz, None, sc.tgt_cov)
+    reg.set_source(sc.src_xyz, None, sc.src_cov)
+    T, res = reg.register(np.eye(4))
+    ids, d2, w = reg.correspondences()
+    reg.close()
+    return T, res, ids, d2, w
+
+
+def test_gicp_persistent_tail_equals_the_select_based_gicp_iteration():
+    """GICP (B1) with the coherence shortcut: from its second iteration on the registration runs inside the persistent tail
+    kernel (k_tail<true>: per-point shortcut test, own searches, the fp64 GICP factor of k_linearize_gicp, one exchange, the
+    GICP solve / se(3) update / stop rules on every workgroup).  Against the select-based iteration (disable_fused): same
+    iteration count and flags, ids and d2 of the last evaluation bit for bit (the shortcut never changes a match), poses
+    within 1e-6 (the 32 fp64 sums are added in a different order) -- for the epsilon rule, Open3D's relative rule, a run cut
+    off by max_iter, a fixed count, and sizes from one workgroup to all 256."""
+    cases = [(60, 300, dict(fixed_iters=6, max_dist=2.0)), (700, 9000, dict(max_iter=30)), (6000, 60000, dict(max_iter=30)),
+             (6000, 60000, dict(max_iter=40, gicp_stop_rule=1)), (6000, 60000, dict(max_iter=4, gicp_stop_rule=1)),
+             (6000, 60000, dict(max_iter=3)), (24000, 240000, dict(fixed_iters=12)),
+             (70001, 400000, dict(max_iter=25, gicp_stop_rule=1, max_dist=0.3))]
+    for n_src, n_tgt, kw in cases:
+        sc = synth.make_scene(n_src, n_tgt, seed=31 + n_src % 7)
+        kw = dict(kw)
+        md = kw.pop("max_dist", 0.5)
+        Tt, rt, idt, d2t, wt = _register_gicp(sc, md, **kw)
+        Tg, rg, idg, d2g, wg = _register_gicp(sc, md, disable_fused=1, **kw)
+        assert rt.n_tail_launches >= 1 and rg.n_tail_launches == 0, (n_src, kw, rt.n_tail_launches)
+        assert rt.iterations == rg.iterations, (n_src, kw, rt.iterations, rg.iterations)
+        assert bool(rt.converged) == bool(rg.converged) and bool(rt.max_iter_reached) == bool(rg.max_iter_reached)
+        assert np.array_equal(idt, idg) and np.array_equal(d2t.view(np.uint32), d2g.view(np.uint32)), (n_src, kw)
+        assert np.array_equal(wt, wg)
+        assert np.abs(Tt - Tg).max() <= 1e-6, (n_src, kw, np.abs(Tt - Tg).max())
+        assert rt.n_matched == rg.n_matched and abs(rt.error - rg.error) <= 1e-9 * max(rg.error, 1e-30)
+        assert np.allclose(np.array(rt.T_iter_prev), np.array(rg.T_iter_prev), atol=1e-6)
