@@ -97,6 +97,7 @@ static reg_status prepare_rowmajor(reg_handle* h, const float* T_init_row, const
     pmark("prepare_source");
     HIPCHK(h, hipGetLastError());
     h->prepared = true;
+    h->match_launches = 0;
     h->have_match = false;
     return REG_OK;
 }
@@ -213,11 +214,15 @@ static reg_status enqueue_match(reg_handle* h, bool zero_hist = false) {
         uint8_t* hint = h->dbg.match_variant == 2 ? nullptr : h->i_hint.as<uint8_t>();
         const int lanes = h->dbg.lanes_per_point == 4 ? 4 : (h->dbg.lanes_per_point == 2 ? 2 : 8);
         const int blocks = grid_for(h->n * lanes);
-        const dim3 grid(8 * ((blocks + 7) / 8)), block(256);
+        // first searches of a registration: tiles large enough to keep an XCD's L2 on one region of the reference; later ones (halo
+        // runs): finer
+        const int tile = h->match_launches < 2 ? h->env.xcd_tile_first : h->env.xcd_tile_later;
+        ++h->match_launches;
+        const dim3 grid(xcd_tiled_grid(blocks, tile)), block(256);
         auto go = [&](auto kernel) {
             launch_timed(h, 0, kernel, grid, block, (const float4*)h->s_xyz.as<float4>(), h->n, it, h->grid,
                          h->i_pos.as<int>(), h->i_d2.as<float>(), hist0, hist2, hint, h->shift0, h->dbg.debug_flags, blocks,
-                         h->i_cache.as<float4>());
+                         h->i_cache.as<float4>(), tile);
         };
         if (lanes == 4)
             go(k_match_g8<4>);

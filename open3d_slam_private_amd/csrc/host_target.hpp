@@ -46,6 +46,8 @@ struct EnvSwitches {
     int tail_wpc = 0;           // O3D_TAIL_WPC: cap on the tail kernel's workgroups per XCD class (0: CUs / 8)
     double dist_timeout_s = 30.0; // O3D_DIST_TIMEOUT_S: deadline of every wait of the distributed path
     float tail_timeout_s = 2.f; // O3D_TAIL_TIMEOUT_S: bound of every grid barrier of the tail kernel
+    int xcd_tile_first = 32;      // O3D_XCD_TILE_FIRST / _LATER: workgroups per XCD tile of the search kernel, first two launches of a
+    int xcd_tile_later = 16;      //   registration / later ones (0: one contiguous eighth of the reading per XCD)
     bool no_gicp_tail = false;    // O3D_NO_GICP_TAIL=1: GICP stays on its select-based iteration
     int gicp_tail_after = 1;      // O3D_GICP_TAIL_AFTER: select-based GICP iterations before the tail kernel takes over
     float tail_settle_tol = 1.2f; // O3D_TAIL_SETTLE: relative change of the trimmed limit below which the tail kernel takes over
@@ -74,6 +76,8 @@ struct EnvSwitches {
         if (const char* v = getenv("O3D_DIST_TIMEOUT_S")) dist_timeout_s = std::max(0.5, atof(v));
         if (const char* v = getenv("O3D_TAIL_SETTLE")) tail_settle_tol = (float)atof(v);
         if (const char* v = getenv("O3D_NO_GICP_TAIL")) no_gicp_tail = atoi(v) != 0;
+        if (const char* v = getenv("O3D_XCD_TILE_FIRST")) xcd_tile_first = std::max(0, atoi(v));
+        if (const char* v = getenv("O3D_XCD_TILE_LATER")) xcd_tile_later = std::max(0, atoi(v));
         if (const char* v = getenv("O3D_GICP_TAIL_AFTER")) gicp_tail_after = atoi(v);
         if (const char* v = getenv("O3D_TAIL_TIMEOUT_S")) tail_timeout_s = std::min(30.f, std::max(0.01f, (float)atof(v)));
         if (const char* v = getenv("O3D_KAHEAD")) lookahead = std::max(1, atoi(v));
@@ -150,6 +154,7 @@ struct reg_handle {
     const uint32_t* perm = nullptr;   // slot -> input index (null: identity)
     int last_stalls = 0;
     int64_t n_total_hint = 0;   // multi-GPU: points of the WHOLE reading (fitness of the GICP stop rule); 0: this handle's n
+    int match_launches = 0;   // search launches since the reading was prepared (picks the XCD tile)
     int last_tail_launches = 0, last_tail_iters = 0;   // persistent tail: launches / iterations of the last reg_register
     DevBuf i_tail_sync, i_tail_rows, i_tail_band;      // persistent tail: counters | per-workgroup sum rows | band records
     unsigned long long dist_seq0 = 0;

@@ -39,6 +39,9 @@ k_match(const float4* __restrict__ src, int64_t n, const IterState* __restrict__
 }
 
 // LDS words per group for the wide level scan (segment starts + exclusive offsets + sentinel)
+#ifndef O3D_MATCH_REGROUP
+#define O3D_MATCH_REGROUP 1
+#endif
 template <int G>
 constexpr int kSegWords = (2 * G * kSegPerLane + 2 + 3) & ~3;   // a multiple of 4 words: 16-byte aligned rows (the fused kernel reuses a row as float4s)
 
@@ -50,10 +53,11 @@ k_match_g8(const float4* __restrict__ src, int64_t n, const IterState* __restric
            float* __restrict__ d2, uint32_t* __restrict__ hist0 /* 2048 or null */,
            uint32_t* __restrict__ hist2_to_zero, uint8_t* __restrict__ hint, int shift0, int debug, int n_blocks,
            float4* __restrict__ cache /* 4 x n, or null: anchor + bound (row 0; row 3 = "no runner-up on record") for the
-                                         temporal-coherence shortcut of the fused iterations (k_coh_check) */) {
+                                         temporal-coherence shortcut of the fused iterations (k_coh_check) */,
+           int xcd_tile /* workgroups per XCD tile (xcd_block_tiled) */) {
     __shared__ uint32_t sh[2048];
     __shared__ __attribute__((aligned(16))) uint32_t seg_lds[(256 / G) * kSegWords<G>];
-    const int lb = xcd_block(n_blocks);
+    const int lb = xcd_block_tiled(n_blocks, xcd_tile);
     const int64_t tid = lb * (int64_t)blockDim.x + threadIdx.x;
     const int64_t q = lb < n_blocks ? (tid / G) : n;
     const int sub = (int)(tid & (G - 1));
@@ -74,37 +78,96 @@ k_match_g8(const float4* __restrict__ src, int64_t n, const IterState* __restric
         for (int k = threadIdx.x; k < 2048; k += blockDim.x) sh[k] = 0;
         __syncthreads();
     }
+    if (debug & 4) {  // timing experiment: fixed cost of the launch + reading load only
+        if (q < n && sub == 0) {
+            pos[q] = -1;
+            d2[q] = xf_point(T, s.x, s.y, s.z).x;
+        }
+        return;
+    }
+    auto emit = [&](int64_t qq, const float3 pp, const Best& b, int lvl, float cov2) {
+        pos[qq] = b.pos;
+        d2[qq] = b.pos >= 0 ? b.d2 : INFINITY;
+        if (hint) hint[qq] = (uint8_t)(lvl + 1);
+        if (cache) {
+            cache[qq] = make_float4(pp.x, pp.y, pp.z, b.pos >= 0 ? fminf(b.second, cov2) : -1.f);
+            cache[3 * (size_t)n + qq] = make_float4(0.f, 0.f, 0.f, 0.f);   // no runner-up on record: one-candidate bound
+        }
+        if (hist0 && b.pos >= 0) atomicAdd(&sh[__float_as_uint(b.d2) >> shift0], 1u);
+    };
+    // Two parts.  (1) Every query tries the halo level (one lookup, one short run: after a pose update most neighbours are back
+    // within its radius even when the previous search needed a large box; hint h >= 2: the last search ended at regular level
+    // h - 1 -> if the halo cannot answer, continue one regular level below that).  (2) The queries the halo could not answer
+    // are REGROUPED through LDS, ordered by the level they continue at (those that hold a halo candidate -- exactly one more
+    // level scan -- in front of those that do not): a wave pays for the level scans of its slowest group, so unanswered queries
+    // spread one or two per wave kept every wave of the workgroup in the level code (iteration 1 at C3: 27 % of the queries,
+    // 92 % of the waves); packed, the waves behind them retire after the halo part and groups of a wave run alike.
+    // (one-candidate bound here: tracking the runner-up's identity in this kernel -- whose first launches scan hundreds of
+    // candidates per point -- cost it 20 %, more than the fused iterations gain from the tighter bound; the fused iterations'
+    // own searches, k_coh_search, do track it)
+    constexpr int kP = 256 / G;               // queries of this workgroup
+    constexpr int kKeys = 2 * kMaxLevels + 2;
+    __shared__ float4 un_p[kP], un_b[kP];     // {p, cov}, {d2, idx, pos, second} of the unanswered queries, in their new order
+    __shared__ uint32_t un_l[kP];             // level | local query << 8
+    __shared__ uint32_t key_cnt[kKeys + 1];
+    const int grp = (int)(threadIdx.x / G);
+    const int gbase = (int)(threadIdx.x & 63) & ~(G - 1);
+    for (int k = threadIdx.x; k <= kKeys; k += blockDim.x) key_cnt[k] = 0u;
+    __syncthreads();
+    const float3 p = xf_point(T, s.x, s.y, s.z);
+    Best b;
+    float cov = 0.f, cov2 = 0.f;
+    int l = 0, lvl = 0, key = -1;
+    uint32_t rnk = 0;
     if (q < n) {
-        const float3 p = xf_point(T, s.x, s.y, s.z);
-        if (debug & 4) {  // timing experiment: fixed cost of the launch + reading load only
-            if (sub == 0) {
-                pos[q] = -1;
-                d2[q] = p.x;
-            }
-            return;
-        }
-        // The halo level is always tried first (one lookup, one short run: after a pose update most neighbours are
-        // back within its radius even when the previous search needed a large box -- hints otherwise decay by only one
-        // level per iteration; measured -2 % on C2).  hint h >= 2: the last search ended at regular level h-1 -> if the
-        // halo cannot answer, continue one regular level below that.
         const int hv = hint ? (int)hraw : 0;
-        int lvl;
-        float cov2;
-        // (one-candidate bound here: tracking the runner-up's identity in this kernel -- whose first launches scan thousands
-        // of candidates per point -- cost it 20 %, more than the fused iterations gain from the tighter bound; the fused
-        // iterations' own searches, k_coh_search, do track it)
-        const Best b = nearest_group<G, true>(g, p, sub, -1, &lvl, seg_lds + (threadIdx.x / G) * kSegWords<G>,
-                                        hv >= 2 ? hv - 2 : -1, &cov2);
-        if (sub == 0) {
-            pos[q] = b.pos;
-            d2[q] = b.pos >= 0 ? b.d2 : INFINITY;
-            if (hint) hint[q] = (uint8_t)(lvl + 1);
-            if (cache) {
-                cache[q] = make_float4(p.x, p.y, p.z, b.pos >= 0 ? fminf(b.second, cov2) : -1.f);
-                cache[3 * (size_t)n + q] = make_float4(0.f, 0.f, 0.f, 0.f);   // no runner-up on record: one-candidate bound
-            }
-            if (hist0 && b.pos >= 0) atomicAdd(&sh[__float_as_uint(b.d2) >> shift0], 1u);
+        if (nearest_halo<G, false>(g, p, sub, gbase, -1, hv >= 2 ? hv - 2 : -1, b, cov, l, &lvl, &cov2)) {
+            if (sub == 0) emit(q, p, b, lvl, cov2);
+#if !O3D_MATCH_REGROUP
+        } else if (true) {   // A/B: the levels at once, by the same lanes
+            b = nearest_levels<G, true, false>(g, p, sub, gbase, l, b, cov, seg_lds + grp * kSegWords<G>, 0.f, &lvl, &cov2);
+            if (sub == 0) emit(q, p, b, lvl, cov2);
+#endif
+        } else {
+            key = min(l, kMaxLevels) + (b.pos >= 0 ? 0 : kMaxLevels + 1);
+            if (sub == 0) rnk = atomicAdd(&key_cnt[key], 1u);
+            rnk = (uint32_t)__shfl((int)rnk, gbase);
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {   // exclusive prefix of the key counts (wave 0)
+        const uint32_t c = (int)threadIdx.x < kKeys ? key_cnt[threadIdx.x] : 0u;
+        uint32_t incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
+            if ((int)threadIdx.x >= o) incl += v;
+        }
+        if ((int)threadIdx.x < kKeys) key_cnt[threadIdx.x] = incl - c;
+        if (threadIdx.x == kKeys - 1) key_cnt[kKeys] = incl;
+    }
+    __syncthreads();
+    if (key >= 0 && sub == 0) {
+        const uint32_t at = key_cnt[key] + rnk;
+        un_p[at] = make_float4(p.x, p.y, p.z, cov);
+        un_b[at] = make_float4(b.d2, __uint_as_float(b.idx), __int_as_float(b.pos), b.second);
+        un_l[at] = (uint32_t)l | ((uint32_t)grp << 8);
+    }
+    __syncthreads();
+    if (grp < (int)key_cnt[kKeys]) {
+        const float4 ep = un_p[grp], eb = un_b[grp];
+        const uint32_t el = un_l[grp];
+        const int64_t q2 = (int64_t)lb * kP + (int64_t)(el >> 8);
+        const float3 p2 = make_float3(ep.x, ep.y, ep.z);
+        Best b2;
+        b2.d2 = eb.x;
+        b2.idx = __float_as_uint(eb.y);
+        b2.pos = __float_as_int(eb.z);
+        b2.second = eb.w;
+        b2.pos2 = -1;
+        b2.third = INFINITY;
+        b2 = nearest_levels<G, true, false>(g, p2, sub, gbase, (int)(el & 255u), b2, ep.w, seg_lds + grp * kSegWords<G>, 0.f, &lvl, &cov2);
+        if (sub == 0) emit(q2, p2, b2, lvl, cov2);
     }
     if (hist0) {
         __syncthreads();

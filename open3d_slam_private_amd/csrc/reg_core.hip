@@ -50,3 +50,16 @@ using namespace o3dreg;
 #include "host_loop.hpp"
 #include "host_dist.hpp"
 #include "host_rccl.hpp"
+
+#if O3D_SEARCH_STATS
+// diagnostic builds only: read (and clear) the search counters of reg_kernels.hpp
+extern "C" __attribute__((visibility("default"))) int o3d_debug_search_stats(unsigned long long out[64], int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(o3dreg::g_search_stats), 512) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[64] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(o3dreg::g_search_stats), z, 512) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

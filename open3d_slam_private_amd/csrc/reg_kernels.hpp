@@ -205,6 +205,32 @@ __device__ __forceinline__ Best nearest(const Grid& g, float3 p) {
 // -------------------------------------------------------------------------------------------------
 constexpr int kGroup = 8;   // default group width (lanes per reading point); kernels are templated on it
 
+#ifndef O3D_SEARCH_STATS
+#define O3D_SEARCH_STATS 0   // diagnostic A/B builds only (tools/build_ab.sh -DO3D_SEARCH_STATS=1, tools/tools_search_stats.py)
+#endif
+#if O3D_SEARCH_STATS
+// [0] level scans [1] bricks of their boxes [2] non-empty rows inside the boxes [3] rows kept by the ball [4] candidates
+// looked at [5] batches (phase 1 + compaction + flattened scan) [6] halo candidates [7] searches
+__device__ unsigned long long g_search_stats[64];   // [8..23] level scans by log2(candidates + 1), [24..39] by log2(rows kept + 1), [40..55] by log2(bricks + 1)
+#define SEARCH_STAT(i, v) atomicAdd(&g_search_stats[i], (unsigned long long)(v))
+// wave time by section of the search ([56 + i], s_memtime ticks of 10 ns; whoever is executing stamps: divergent groups of a wave
+// take their turns, each turn is charged to the section it runs): 0 halo run, 1 level box + brick directory, 2 row slots
+// (phase 1), 3 compaction, 4 flattened candidate scan, 5 group minimum + level logic, 6 ball update
+__device__ __forceinline__ void search_sec(int i) {
+    __shared__ unsigned long long last_w[16];
+    const unsigned long long now = __builtin_amdgcn_s_memtime();
+    const int w = (int)(threadIdx.x >> 6);
+    if ((int)(threadIdx.x & 63) == __ffsll((unsigned long long)__ballot(1)) - 1) {
+        if (i >= 0) atomicAdd(&g_search_stats[56 + i], now - last_w[w]);
+        last_w[w] = now;
+    }
+}
+#define SEARCH_SEC(i) search_sec(i)
+#else
+#define SEARCH_STAT(i, v)
+#define SEARCH_SEC(i)
+#endif
+
 template <bool kTop2 = false>
 __device__ __forceinline__ void consider(const Grid& g, float3 p, const float4 t, int j, Best& best) {
     const float dx = p.x - t.x, dy = p.y - t.y, dz = p.z - t.z;
@@ -410,6 +436,19 @@ __device__ __forceinline__ Best group_min_lazy(const Grid& g, Best b, int gbase)
 #endif
 constexpr int kSegPerLane = O3D_SEG_PER_LANE;
 
+// a / b and a % b for 0 <= a < 2^20, 1 <= b <= a + 1: fp32 reciprocal estimate (off by at most one), corrected exactly
+__device__ __forceinline__ void fast_divmod(int a, int b, int& q, int& r) {
+    q = (int)((float)a * __builtin_amdgcn_rcpf((float)b));
+    r = a - q * b;
+    if (r < 0) {
+        --q;
+        r += b;
+    } else if (r >= b) {
+        ++q;
+        r -= b;
+    }
+}
+
 // index of the k-th (0-based) set bit of the 64-bit mask {lo, hi}; k < popcount
 __device__ __forceinline__ int nth_set_bit64(uint32_t lo, uint32_t hi, int k) {
     int c = __popc(lo), base = 0;
@@ -469,6 +508,7 @@ __device__ __forceinline__ float scan_level_rows(const Grid& g, const float3 p, 
     const int nbxy = nbx * nby;
     const int n_bricks = nbxy * nbz;
     const bool pk_ok = nbx <= 1024 && nby <= 1024 && nbz <= 1024;
+    const bool small_box = n_bricks < (1 << 20);
     const unsigned gmask = (1u << G) - 1u;
     // Ball pruning (exact): a bin box holds ~2x the volume of the ball it covers.  Rows whose (y, z) bin interval lies
     // farther than the box radius from the query are skipped and the others are cut to the x-range the ball reaches, in BIN
@@ -478,10 +518,15 @@ __device__ __forceinline__ float scan_level_rows(const Grid& g, const float3 p, 
     // set, which is all the termination test (best d2 <= rho^2 < rho_box^2) relies on.
     constexpr float kPruneSlack = 4e-3f;
     const bool prune = kPrune && g.dimx <= 8192 && g.dimy <= 8192 && g.dimz <= 8192;
+#if O3D_SEARCH_STATS
+    if (sub == 0) SEARCH_STAT(0, 1);
+    unsigned stat_pts = 0, stat_rows = 0;
+#endif
     const float fxq = (p.x - g.ox) * g.inv_c, fyq = (p.y - g.oy) * g.inv_c, fzq = (p.z - g.oz) * g.inv_c;
     float rbb = rb * g.inv_c + kPruneSlack;
     float rb2 = rbb * rbb;
     for (int cb = 0; cb < n_bricks; cb += G) {
+        SEARCH_SEC(5);
         // ---- this lane's brick of the chunk: directory entry + row mask (one batch of independent loads)
         const int bi = cb + sub;
         int bid = -1;
@@ -491,8 +536,16 @@ __device__ __forceinline__ float scan_level_rows(const Grid& g, const float3 p, 
                             // each (~45 of the ~140 VALU instructions a slot cost: the level scans of the first iterations are
                             // bound by this enumeration, not by their candidates -- profiles/r03_counters_c3_per_dispatch.txt)
         if (bi < n_bricks) {
-            const int iz = bi / nbxy, rem = bi - iz * nbxy;
-            const int iy = rem / nbx, ix = rem - iy * nbx;
+            int iz, rem, iy, ix;
+            if (small_box) {   // (group-uniform) quotient by a float reciprocal, corrected: two integer divisions cost ~70 instructions
+                fast_divmod(bi, nbxy, iz, rem);
+                fast_divmod(rem, nbx, iy, ix);
+            } else {
+                iz = bi / nbxy;
+                rem = bi - iz * nbxy;
+                iy = rem / nbx;
+                ix = rem - iy * nbx;
+            }
             bpk = (uint32_t)ix | ((uint32_t)iy << 10) | ((uint32_t)iz << 20);   // (boxes wider than 1024 bricks: decoded below)
             const int bx = bx0 + ix, by = by0 + iy, bz = bz0 + iz;
             const size_t at = ((size_t)bz * g.bdy + by) * g.bdx + bx;
@@ -517,8 +570,15 @@ __device__ __forceinline__ float scan_level_rows(const Grid& g, const float3 p, 
             if (sub >= o) incl += v;
         }
         const int total = (int)(uint32_t)__shfl((int)incl, gbase + G - 1);
+#if O3D_SEARCH_STATS
+        if (sub == 0) {
+            SEARCH_STAT(1, min(G, n_bricks - cb));
+            SEARCH_STAT(2, total);
+        }
+#endif
         if (total == 0) continue;
         const uint32_t excl = incl - cnt;
+        SEARCH_SEC(1);
         for (int base = 0; base < total; base += CAP) {
             if (prune && g.dyn_prune && g.rho[l] < INFINITY) {
                 // The ball shrinks with the best candidate the GROUP has seen so far (the box was sized before the level
@@ -539,12 +599,15 @@ __device__ __forceinline__ float scan_level_rows(const Grid& g, const float3 p, 
                     }
                 }
             }
+            SEARCH_SEC(6);
             // phase 1: this lane's row segments of the batch -> bin starts (independent loads)
             uint32_t s[S], e[S];
 #pragma unroll
             for (int u = 0; u < S; ++u) {
                 s[u] = 0;
                 e[u] = 0;
+                // (most level scans keep fewer than G rows: slots no group of the wave has are skipped by the whole wave)
+                if (u > 0 && __ballot(base + u * G < total) == 0ull) continue;
                 const int t = base + u * G + sub;
                 // owner lane of slot t (branch-free), then its mask / brick id by lane-indexed shuffles; lanes without a
                 // slot take part in the shuffles with a clamped slot
@@ -592,12 +655,14 @@ __device__ __forceinline__ float scan_level_rows(const Grid& g, const float3 p, 
                 }
             }
             // compact the non-empty segments into the group's LDS list, in segment order
+            SEARCH_SEC(2);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
             uint32_t run_pts = 0, run_seg = 0;
 #pragma unroll
             for (int u = 0; u < S; ++u) {
                 const uint32_t c2 = e[u] - s[u];
+                if (u > 0 && __ballot(c2 != 0u) == 0ull) continue;
                 uint32_t in2 = c2;
 #pragma unroll
                 for (int o = 1; o < G; o <<= 1) {
@@ -614,10 +679,20 @@ __device__ __forceinline__ float scan_level_rows(const Grid& g, const float3 p, 
                 run_pts += tot_u;
                 run_seg += (uint32_t)__popc(m);
             }
+#if O3D_SEARCH_STATS
+            if (sub == 0) {
+                SEARCH_STAT(3, run_seg);
+                SEARCH_STAT(4, run_pts);
+                SEARCH_STAT(5, 1);
+            }
+            stat_pts += run_pts;
+            stat_rows += run_seg;
+#endif
             if (run_pts == 0) continue;
             if (sub == 0) seg_ex[run_seg] = run_pts;   // sentinel: end of the last segment
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
+            SEARCH_SEC(3);
             // phase 2: flattened scan, 4 independent 16-byte loads in flight per lane
             uint32_t k = 0, cur_ex = 0, cur_st = seg_st[0], next_ex = seg_ex[1];
             constexpr int kUnroll = O3D_SCAN_UNROLL;
@@ -639,8 +714,17 @@ __device__ __forceinline__ float scan_level_rows(const Grid& g, const float3 p, 
 #pragma unroll
                 for (int u = 0; u < kUnroll; ++u) consider<kTop2>(g, p, tv[u], (int)jv[u], best);
             }
+            SEARCH_SEC(4);
         }
     }
+    SEARCH_SEC(1);
+#if O3D_SEARCH_STATS
+    if (sub == 0) {
+        SEARCH_STAT(8 + min(15, 32 - __clz((int)stat_pts)), 1);
+        SEARCH_STAT(24 + min(15, 32 - __clz((int)stat_rows)), 1);
+        SEARCH_STAT(40 + min(15, 32 - __clz(n_bricks)), 1);
+    }
+#endif
     return cover;
 }
 
@@ -660,20 +744,25 @@ __device__ __forceinline__ float scan_level_rows(const Grid& g, const float3 p, 
 // Best::second this bounds how close any point other than the winner can be: d2(x) >= min(second, cov2) for all x != best
 // (the temporal-coherence shortcut of the next iterations relies on it; `slack` widens candidate-bounded boxes a little so
 // that the bound is not just the winner's own distance).
-template <int G, bool kPrune = false, bool kTop2 = false>
-__device__ __forceinline__ Best nearest_group(const Grid& g, float3 p, int sub, int first_level, int* level_out,
-                                              uint32_t* seg, int after_halo = -1, float* cov2_out = nullptr,
-                                              float slack = 0.f) {
-    Best best;
+// Halo part of the search: one dense-grid lookup, one contiguous run.  Returns true when the halo level answered the query
+// (level -1); otherwise `best` (the group's merged candidate of the halo run, if any, the same in every lane), `cov` and the regular
+// level `l` to continue at are what nearest_levels() needs -- by the same lanes or, handed over through LDS, by another group
+// (k_match_g8 regroups the unanswered queries of a workgroup so that whole waves are done after the halo part).
+template <int G, bool kTop2>
+__device__ __forceinline__ bool nearest_halo(const Grid& g, float3 p, int sub, int gbase, int first_level, int after_halo, Best& best,
+                                             float& cov, int& l, int* level_out, float* cov2_out) {
     best.d2 = INFINITY;
     best.idx = 0xffffffffu;
     best.pos = -1;
     best.second = INFINITY;
     best.pos2 = -1;
     best.third = INFINITY;
-    float cov = 0.f;   // radius covered so far
-    const int gbase = (int)(threadIdx.x & 63) & ~(G - 1);  // first lane of this group in the wave
-    int l = min(first_level, g.n_levels - 1);
+    cov = 0.f;   // radius covered so far
+#if O3D_SEARCH_STATS
+    if (sub == 0) SEARCH_STAT(7, 1);
+    SEARCH_SEC(-1);
+#endif
+    l = min(first_level, g.n_levels - 1);
     if (g.use_halo && first_level < 0) {
         // halo level: one dense-grid lookup, one contiguous run
         const float fx = bin_coord_f(p.x, g.hox, g.hinv_c), fy = bin_coord_f(p.y, g.hoy, g.hinv_c),
@@ -684,6 +773,9 @@ __device__ __forceinline__ Best nearest_group(const Grid& g, float3 p, int sub, 
         if (inside) {
             const size_t B = ((size_t)(int)fz * g.hdimy + (int)fy) * g.hdimx + (int)fx;
             const uint32_t s = g.halo_start[B], e = g.halo_start[B + 1];
+#if O3D_SEARCH_STATS
+            if (sub == 0) SEARCH_STAT(6, e - s);
+#endif
             constexpr int kU = O3D_HALO_UNROLL;
             for (uint32_t j0 = s; j0 < e; j0 += kU * G) {
                 float4 tv[kU];
@@ -693,6 +785,7 @@ __device__ __forceinline__ Best nearest_group(const Grid& g, float3 p, int sub, 
                 for (int u = 0; u < kU; ++u) consider_pos<kTop2>(g, p, tv[u], best);
             }
             best = group_min_lazy<G, kTop2>(g, best, gbase);
+            SEARCH_SEC(0);
             const float rh = g.rho_h;
             const float rh2 = rh * rh;
             cov = rh;
@@ -701,7 +794,7 @@ __device__ __forceinline__ Best nearest_group(const Grid& g, float3 p, int sub, 
                 // (capped at max_dist: points beyond it are not candidates, hence not in `second` either -- found by the
                 // round-2 fuzz: halo radius 0.24 m with maxDist 0.2 m let a point 0.22 m away go unnoticed by the bound)
                 if (cov2_out) *cov2_out = fminf(rh2, g.max_d2);
-                return best;
+                return true;
             }
             if (best.pos >= 0 && best.idx == 0xffffffffu) best.idx = __float_as_uint(g.pts[best.pos].w);
             if (best.pos >= 0) {
@@ -714,6 +807,13 @@ __device__ __forceinline__ Best nearest_group(const Grid& g, float3 p, int sub, 
         }
     }
     l = max(max(l, after_halo), 0);   // no halo level (or the query lies outside its grid): the hinted level
+    return false;
+}
+
+// Regular levels, from level `l` on, continuing from the state nearest_halo() left.
+template <int G, bool kPrune, bool kTop2>
+__device__ __forceinline__ Best nearest_levels(const Grid& g, float3 p, int sub, int gbase, int l, Best best, float cov, uint32_t* seg,
+                                               float slack, int* level_out, float* cov2_out) {
     for (; l < g.n_levels; ++l) {
         cov = fmaxf(cov, scan_level_rows<G, kPrune, kTop2>(g, p, sub, gbase, l, seg, best, slack));
         best = group_min<G, kTop2>(best);
@@ -729,9 +829,22 @@ __device__ __forceinline__ Best nearest_group(const Grid& g, float3 p, int sub, 
             }
         }
     }
+    SEARCH_SEC(5);
     *level_out = min(l, g.n_levels - 1);
     if (cov2_out) *cov2_out = fminf(cov * cov, g.max_d2);
     return best;
+}
+
+template <int G, bool kPrune = false, bool kTop2 = false>
+__device__ __forceinline__ Best nearest_group(const Grid& g, float3 p, int sub, int first_level, int* level_out,
+                                              uint32_t* seg, int after_halo = -1, float* cov2_out = nullptr,
+                                              float slack = 0.f) {
+    Best best;
+    float cov;
+    int l;
+    const int gbase = (int)(threadIdx.x & 63) & ~(G - 1);  // first lane of this group in the wave
+    if (nearest_halo<G, kTop2>(g, p, sub, gbase, first_level, after_halo, best, cov, l, level_out, cov2_out)) return best;
+    return nearest_levels<G, kPrune, kTop2>(g, p, sub, gbase, l, best, cov, seg, slack, level_out, cov2_out);
 }
 
 }  // namespace o3dreg

@@ -90,6 +90,22 @@ __device__ __forceinline__ int xcd_block(int n_blocks) {
     return (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
 }
 
+// ... in tiles: XCD x takes tiles x, x + 8, x + 16, ... of `tile` consecutive workgroups each.  One contiguous eighth per XCD
+// ties the time of a launch to its slowest eighth: the first searches of a registration cost most where the initial guess is
+// farthest off (rotation error x range), and that is ONE corner of the Morton-ordered reading (C3, second search launch:
+// 160 us with eighths, 117 us in tiles of 16).  Launch with xcd_tiled_grid(n_blocks, tile) workgroups; tile <= 0: eighths.
+__host__ __device__ __forceinline__ int xcd_tiled_grid(int n_blocks, int tile) {
+    if (tile <= 0) return 8 * ((n_blocks + 7) / 8);
+    const int per = 8 * tile;
+    return per * ((n_blocks + per - 1) / per);
+}
+__device__ __forceinline__ int xcd_block_tiled(int n_blocks, int tile) {
+    if (tile <= 0) return xcd_block(n_blocks);
+    const int xcd = (int)(blockIdx.x & 7), j = (int)(blockIdx.x >> 3);
+    const int t = j / tile, r = j - t * tile;
+    return (t * 8 + xcd) * tile + r;
+}
+
 struct Xf4 {
     float m[16];
 };
