@@ -327,10 +327,12 @@ REG_API void reg_host_x_to_T(const float x[6], float T[16]);
 REG_API int  reg_host_solve6_xicp(const float A[36], const float b[6], const int32_t flags[6], float x[6]);
 REG_API void reg_host_centroid(const float* xyz, int64_t stride, int64_t n, float out[3]);
 /* Launch plan of the persistent tail kernel (csrc/kernels_tail.hpp) for a reading of n points on a device with `cus`
-   compute units: plan = {usable (0/1), workgroups, workgroups per XCD class, reading points per XCD class}.  Slot s of
-   workgroup b holds reading point (b & 7) * plan[3] + (((s >> 3) * plan[2] + (b >> 3)) << 3) + (s & 7) when that lies inside
-   the class's share and below n (1024 slots per workgroup).  Host-only: lets the slot <-> point mapping be checked on CPU. */
-REG_API void reg_host_tail_plan(int64_t n, int32_t cus, int32_t plan[4]);
+   compute units: plan = {usable (0/1), workgroups, workgroups per XCD class, reading points per XCD class}.  Octet
+   oc = (s >> 3) * plan[2] + (b >> 3) of XCD class x = b & 7 is, with tile == 0, octet oc of the class's contiguous share
+   (reading point x * plan[3] + 8 * oc + (s & 7)); with tile > 0 the classes take turns in tiles of `tile` octets: reading point
+   8 * (((oc / tile) * 8 + x) * tile + oc % tile) + (s & 7).  Valid when 8 * oc + (s & 7) < plan[3] and the point lies below n
+   (1024 slots per workgroup).  Host-only: lets the slot <-> point mapping be checked on CPU. */
+REG_API void reg_host_tail_plan(int64_t n, int32_t cus, int32_t tile, int32_t plan[4]);
 
 /* Measurement hook (bench.py roofline object): average device time in ms, by HIP events on the handle's
    stream, of [0] the match kernel, [1] the trimmed-quantile select passes, [2] linearize + final reduce. */

@@ -708,12 +708,12 @@ def host_centroid(xyz):
     return out
 
 
-def host_tail_plan(n, cus=256):
+def host_tail_plan(n, cus=256, tile=0):
     """Launch plan of the persistent tail kernel for an n-point reading: (usable, workgroups, workgroups per XCD class, reading
-    points per XCD class) -- host-only (reg_host_tail_plan)."""
+    points per XCD class) -- host-only (reg_host_tail_plan).  tile: octets per XCD tile (0: contiguous eighths)."""
     lib = load_library()
-    lib.reg_host_tail_plan.argtypes = [C.c_int64, C.c_int32, C.POINTER(C.c_int32)]
+    lib.reg_host_tail_plan.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
     lib.reg_host_tail_plan.restype = None
     out = (C.c_int32 * 4)()
-    lib.reg_host_tail_plan(int(n), int(cus), out)
+    lib.reg_host_tail_plan(int(n), int(cus), int(tile), out)
     return bool(out[0]), int(out[1]), int(out[2]), int(out[3])

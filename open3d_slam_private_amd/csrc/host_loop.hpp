@@ -63,7 +63,8 @@ static reg_status prepare_rowmajor(reg_handle* h, const float* T_init_row, const
         sums = h->s_misc.as<unsigned long long>() + (h->cent_slot ? 16 : 8);
         sums_next = h->s_misc.as<unsigned long long>() + (h->cent_slot ? 8 : 16);
         h->cent_slot ^= 1;
-        const int blocks = (int)std::min<int64_t>(1024, (n + 255) / 256);
+        // (one workgroup per CU: every workgroup ends in three atomics on ONE cache line, ~15 ns each, one after the other)
+        const int blocks = (int)std::min<int64_t>(256, (n + 255) / 256);
         k_centroid_sums<<<blocks, 256, 0, h->stream>>>(h->s_raw.as<float>(), h->s_stride, n, sums);
     }
     pmark("centroid");
@@ -379,7 +380,7 @@ static std::mutex g_tail_probe_mutex;
 
 struct TailPlan {
     bool ok = false;
-    int grid = 0, wpc = 0, chunk8 = 0;
+    int grid = 0, wpc = 0, chunk8 = 0, tile = 0;
 };
 
 // CUs of the device if one k_tail workgroup fits on each (occupancy query), probed once per process and device.
@@ -403,19 +404,23 @@ static int tail_device_cus(int dev) {
     return g_tail_cus[dev];
 }
 
-static TailPlan tail_plan_for(int64_t n, int cus, int wpc_cap) {
+static TailPlan tail_plan_for(int64_t n, int cus, int wpc_cap, int tile) {
     TailPlan pl;
     if (cus < 8 || n <= 0) return pl;
     int wpc_max = cus / 8;
     if (wpc_cap > 0) wpc_max = std::min(wpc_max, wpc_cap);
     pl.wpc = (int)std::max<int64_t>(1, std::min<int64_t>(wpc_max, (n + 2047) / 2048));
-    pl.chunk8 = (int)((((n + 7) / 8) + 7) / 8 * 8);
+    pl.tile = std::max(0, tile);
+    const int64_t unit = 8 * (int64_t)std::max(1, pl.tile);   // points per XCD class: whole octets, whole tiles
+    pl.chunk8 = (int)((((n + 7) / 8) + unit - 1) / unit * unit);
     const int64_t octets = pl.chunk8 / 8, per_wg = (octets + pl.wpc - 1) / pl.wpc * 8;
     pl.grid = 8 * pl.wpc;
     pl.ok = per_wg <= kTailSlots;
     return pl;
 }
-static TailPlan tail_plan(const reg_handle* h) { return tail_plan_for(h->n, tail_device_cus(h->prm.device), h->env.tail_wpc); }
+static TailPlan tail_plan(const reg_handle* h) {
+    return tail_plan_for(h->n, tail_device_cus(h->prm.device), h->env.tail_wpc, h->env.tail_tile);
+}
 
 static bool tail_eligible(const reg_handle* h) {
     if (h->prm.cost != REG_COST_P2PL && h->env.no_gicp_tail) return false;
@@ -434,6 +439,7 @@ static reg_status enqueue_tail(reg_handle* h, const TailPlan& pl, int max_iters,
     cfg.n = h->n;
     cfg.chunk8 = pl.chunk8;
     cfg.wpc = pl.wpc;
+    cfg.tile = pl.tile;
     cfg.max_iters = std::max(1, std::min(max_iters, kTailMaxIters));
     cfg.slack = coherent_slack(h);
     cfg.seq = ++h->seq;
@@ -572,8 +578,8 @@ static void fill_result(reg_handle* h, const double* sums, reg_result* res) {
 
 extern "C" {
 
-void reg_host_tail_plan(int64_t n, int32_t cus, int32_t plan[4]) {
-    const TailPlan pl = tail_plan_for(n, cus, 0);
+void reg_host_tail_plan(int64_t n, int32_t cus, int32_t tile, int32_t plan[4]) {
+    const TailPlan pl = tail_plan_for(n, cus, 0, tile);
     plan[0] = pl.ok ? 1 : 0;
     plan[1] = pl.grid;
     plan[2] = pl.wpc;

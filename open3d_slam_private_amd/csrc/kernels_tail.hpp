@@ -89,6 +89,7 @@ struct TailCfg {
     int64_t n;
     int chunk8;          // reading points per XCD class (a multiple of 8)
     int wpc;             // workgroups per XCD class (grid = 8 * wpc)
+    int tile;            // octets per XCD tile (0: one contiguous eighth of the reading per XCD class); chunk8 is a multiple of 8 * tile
     int max_iters;       // iterations this launch may run (<= kTailMaxIters)
     float slack;         // candidate-bounded boxes of the fallback searches (see nearest_group)
     unsigned long long seq;
@@ -467,8 +468,16 @@ k_tail(const float4* __restrict__ src, const float4* __restrict__ src_nrm /* GIC
 #pragma unroll
     for (int u = 0; u < kTailPts; ++u) {
         const int sl = t + u * kTailThreads;
-        const int64_t r_in = ((int64_t)(sl >> 3) * cfg.wpc + wq) * 8 + (sl & 7);
-        q[u] = (int64_t)xcls * cfg.chunk8 + r_in;
+        const int64_t oc = (int64_t)(sl >> 3) * cfg.wpc + wq;   // octet inside the XCD class
+        const int64_t r_in = oc * 8 + (sl & 7);
+        if (cfg.tile > 0) {
+            // XCD class x owns tiles x, x + 8, ... of `tile` consecutive octets (see xcd_block_tiled: a contiguous eighth ties every
+            // exchange to the eighth whose shortcut fails most)
+            const int64_t tl = oc / cfg.tile, rr = oc - tl * cfg.tile;
+            q[u] = ((tl * 8 + xcls) * cfg.tile + rr) * 8 + (sl & 7);
+        } else {
+            q[u] = (int64_t)xcls * cfg.chunk8 + r_in;
+        }
         valid[u] = r_in < cfg.chunk8 && q[u] < n;
         if (!valid[u]) q[u] = 0;
     }

@@ -261,23 +261,27 @@ transformationCheckers:
 
 def test_tail_kernel_slot_mapping_covers_every_reading_point_exactly_once():
     """The persistent tail kernel (csrc/kernels_tail.hpp) deals reading points to workgroup slots in octets, round-robin inside an
-    XCD class (blockIdx % 8 keeps one contiguous eighth of the reading).  The plan the host computes and the mapping the kernel
+    XCD class (blockIdx % 8 keeps one contiguous eighth of the reading, or every eighth tile of `tile` octets).  The plan the host computes and the mapping the kernel
     evaluates -- restated here from the header's formula -- must put every point 0 .. n-1 into exactly one (workgroup, slot)."""
-    for n, cus in ((1, 256), (37, 256), (4000, 256), (70001, 256), (100_000, 256), (200_000, 256), (262_144, 256), (50_000, 64),
-                   (262_145, 256), (0, 256), (1000, 4)):
-        ok, grid, wpc, chunk8 = capi.host_tail_plan(n, cus)
+    for n, cus, tile in ((1, 256, 0), (37, 256, 0), (4000, 256, 0), (70001, 256, 0), (100_000, 256, 0), (200_000, 256, 0), (262_144, 256, 0),
+                         (50_000, 64, 0), (262_145, 256, 0), (0, 256, 0), (1000, 4, 0), (37, 256, 4), (4000, 256, 16), (70001, 256, 4),
+                         (200_000, 256, 4), (200_000, 256, 1), (100_000, 256, 32), (262_144, 256, 8), (50_000, 64, 4)):
+        ok, grid, wpc, chunk8 = capi.host_tail_plan(n, cus, tile)
         if n <= 0 or cus < 8:
             assert not ok
             continue
-        assert grid == 8 * wpc and grid <= cus and chunk8 % 8 == 0 and 8 * chunk8 >= n
-        if n > 1024 * grid:
-            assert not ok
+        assert grid == 8 * wpc and grid <= cus and chunk8 % (8 * max(tile, 1)) == 0 and 8 * chunk8 >= n
+        if not ok:
+            assert 8 * ((chunk8 // 8 + wpc - 1) // wpc) > 1024   # a workgroup would need more than its 1024 slots
             continue
-        assert ok, (n, cus)
         b = np.arange(grid)[:, None]
         s = np.arange(1024)[None, :]
-        r_in = (((s >> 3) * wpc + (b >> 3)) << 3) + (s & 7)
-        q = (b & 7) * chunk8 + r_in
+        oc = (s >> 3) * wpc + (b >> 3)
+        r_in = (oc << 3) + (s & 7)
+        if tile > 0:
+            q = 8 * (((oc // tile) * 8 + (b & 7)) * tile + oc % tile) + (s & 7)
+        else:
+            q = (b & 7) * chunk8 + r_in
         valid = (r_in < chunk8) & (q < n)
         hit = np.bincount(q[valid].ravel(), minlength=n)
-        assert hit.shape[0] == n and (hit == 1).all(), (n, cus)
+        assert hit.shape[0] == n and (hit == 1).all(), (n, cus, tile)

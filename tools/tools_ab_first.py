@@ -26,6 +26,7 @@ def make(fixed, profile):
     p.use_xicp = 0
     p.fixed_iters = fixed
     p.profile_loop = profile
+    p.match_variant = int(os.environ.get("AB_MATCH_VARIANT", "0"))
     reg = capi.Registration(p)
     reg.set_target_device(d_t.data_ptr(), 3, n_tgt, d_tn.data_ptr(), 3)
     reg.set_source_device(d_s.data_ptr(), 3, n_src, d_sn.data_ptr(), 3)
