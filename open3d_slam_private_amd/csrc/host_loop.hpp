@@ -455,7 +455,7 @@ static reg_status enqueue_tail(reg_handle* h, const TailPlan& pl, int max_iters,
         const float4* t_attr = gicp ? (const float4*)h->t_cov.as<float4>() : (const float4*)h->t_nrm.as<float4>();
         auto go = [&](auto kernel) {
             launch(kernel, dim3(pl.grid), dim3(kTailThreads), (const float4*)h->s_xyz.as<float4>(), s_attr, h->i_iter.as<IterState>(),
-                   h->grid, t_attr, f, h->i_pos.as<int>(), h->i_d2.as<float>(), w, hint, (const float4*)h->i_cache.as<float4>(),
+                   h->grid, t_attr, f, h->i_pos.as<int>(), h->i_d2.as<float>(), w, hint, h->i_cache.as<float4>(),
                    h->i_tail_sync.as<unsigned>(), h->i_tail_rows.as<double>(), h->i_tail_band.as<float>(), h->d_mirror, cfg);
         };
         if (gicp)

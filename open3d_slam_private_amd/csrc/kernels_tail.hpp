@@ -428,7 +428,7 @@ __global__ void __launch_bounds__(kTailThreads)
 k_tail(const float4* __restrict__ src, const float4* __restrict__ src_nrm /* GICP: the reading's covariances, 2 x float4 */,
        IterState* __restrict__ it_g, Grid g, const float4* __restrict__ tgt_nrm /* GICP: the reference's covariances */,
        FilterCfg f, int* __restrict__ pos_io, float* __restrict__ d2_out,
-       float* __restrict__ w_out, uint8_t* __restrict__ hint_g, const float4* __restrict__ cache, unsigned* __restrict__ sync,
+       float* __restrict__ w_out, uint8_t* __restrict__ hint_g, float4* __restrict__ cache, unsigned* __restrict__ sync,
        double* __restrict__ hist_g /* [2][grid][kTailHistRow] */, float* __restrict__ band_g /* [2][kTailBandCap][12] */,
        HostMirror* host, TailCfg cfg) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -1136,6 +1136,15 @@ k_tail(const float4* __restrict__ src, const float4* __restrict__ src_nrm /* GIC
         d2_out[q[u]] = d2s[sl];
         if (w_out) w_out[q[u]] = w;
         if (hint_g) hint_g[q[u]] = hnt[sl];
+        if (exit_reason == 3) {
+            // out of this launch's iteration budget: the next launch continues from the rows as they stand (anchors, bounds,
+            // matched points and runner-ups of the kernel's own searches), not from what the last select-based iteration left --
+            // a point re-matched in here would otherwise re-enter with its new position next to its old point's row
+            cache[q[u]] = st_rows[sl];
+            cache[(size_t)n + q[u]] = tq;
+            cache[2 * (size_t)n + q[u]] = st_rows[2 * kTailSlots + sl];
+            cache[3 * (size_t)n + q[u]] = st_rows[3 * kTailSlots + sl];
+        }
     }
     if (t == 0 && n_searched) atomicAdd(&sync[kTailSearchedWord], n_searched);
 #if O3D_TAIL_STAMPS

@@ -1155,10 +1155,13 @@ def test_persistent_tail_stall_and_repair_and_iteration_budget():
     T1, r1, *_ = _register(sc, fixed_iters=14, debug_flags=8)
     assert r1.iterations == r0.iterations == 14 and r1.n_band_stalls >= 1 and r1.n_tail_launches >= 1
     assert np.abs(T1 - T0).max() <= 2e-6
-    T2, r2, *_ = _register(sc, fixed_iters=90)
-    T3, r3, *_ = _register(sc, fixed_iters=90, disable_fused=1)
+    T2, r2, id2, d22, w2 = _register(sc, fixed_iters=90)
+    T3, r3, id3, d23, w3 = _register(sc, fixed_iters=90, disable_fused=1)
     assert r2.iterations == r3.iterations == 90 and r2.n_tail_launches >= 2 and r2.n_tail_iterations >= 80
     assert np.abs(T2 - T3).max() <= 2e-6
+    # the second launch continues from the first one's rows (written back when the budget ran out): ids and distances of points
+    # the first launch re-matched stay consistent
+    assert np.array_equal(id2, id3) and np.array_equal(d22.view(np.uint32), d23.view(np.uint32)) and np.array_equal(w2, w3)
 
 
 def _register_gicp(sc, max_dist=0.5, **over):
