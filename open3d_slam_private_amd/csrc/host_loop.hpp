@@ -399,7 +399,7 @@ static int tail_device_cus(int dev) {
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k_tail<false>), kTailThreads, kTailLdsBytes);
     if (e == hipSuccess)
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb2, reinterpret_cast<const void*>(k_tail<true>), kTailThreads, kTailLdsBytes);
-    g_tail_cus[dev] = (e == hipSuccess && nb >= 1 && nb2 >= 1 && cus >= 8) ? cus : -1;
+    g_tail_cus[dev] = (e == hipSuccess && nb >= kTailWgsPerCu && nb2 >= kTailWgsPerCu && cus >= 8) ? cus : -1;
     (void)hipGetLastError();
     return g_tail_cus[dev];
 }
@@ -407,7 +407,7 @@ static int tail_device_cus(int dev) {
 static TailPlan tail_plan_for(int64_t n, int cus, int wpc_cap, int tile) {
     TailPlan pl;
     if (cus < 8 || n <= 0) return pl;
-    int wpc_max = cus / 8;
+    int wpc_max = cus * kTailWgsPerCu / 8;
     if (wpc_cap > 0) wpc_max = std::min(wpc_max, wpc_cap);
     pl.wpc = (int)std::max<int64_t>(1, std::min<int64_t>(wpc_max, (n + 2047) / 2048));
     pl.tile = std::max(0, tile);

@@ -45,7 +45,14 @@
 #endif
 constexpr int kTailThreads = O3D_TAIL_THREADS;   // 8 waves = 2 per SIMD: 256 VGPRs per lane (a 1024-thread workgroup, capped at 128, spilled ~90
                                         // registers around the search and paid a scratch round trip in every phase)
-constexpr int kTailSlots = 1024;        // reading-point slots per workgroup: thread t owns slots t and t + 512
+#ifndef O3D_TAIL_SLOTS
+#define O3D_TAIL_SLOTS 1024
+#endif
+#ifndef O3D_TAIL_WGS_PER_CU
+#define O3D_TAIL_WGS_PER_CU 1
+#endif
+constexpr int kTailSlots = O3D_TAIL_SLOTS;   // reading-point slots per workgroup: thread t owns slots t and t + 512
+constexpr int kTailWgsPerCu = O3D_TAIL_WGS_PER_CU;   // co-resident workgroups per CU the plan may use (launch bounds follow)
 constexpr int kTailPts = kTailSlots / kTailThreads;
 constexpr int kTailBandCap = 1024;     // band records one iteration may hold in all (more: stall, select-based repair)
 constexpr int kTailRec = 12;           // floats per band record: F0..F5, r, d2, kept, 0, kept d2, 0  (= a factor row)
@@ -100,7 +107,10 @@ struct TailCfg {
 struct TailLds {
     static constexpr int kRows = 0;                                   // float4 [5][1024] (row 4: GICP only)
     static constexpr int kUnion = kRows + 5 * kTailSlots * 16;        // segment lists of the searches | ranking keys of the select
-    static constexpr int kUnionBytes = 36864;
+    static constexpr int kUnionSeg = (kTailThreads / 8) * kSegWords<8> * 4, kUnionSeg4 = O3D_TAIL_G4 ? (kTailThreads / 4) * kSegWords<4> * 4 : 0;
+    static constexpr int kUnionMax = kUnionSeg > kUnionSeg4 ? (kUnionSeg > kTailBandCap * 8 ? kUnionSeg : kTailBandCap * 8)
+                                                            : (kUnionSeg4 > kTailBandCap * 8 ? kUnionSeg4 : kTailBandCap * 8);
+    static constexpr int kUnionBytes = (kUnionMax + 255) & ~255;
     static constexpr int kD2 = kUnion + kUnionBytes;                  // float [1024]
     static constexpr int kFail = kD2 + kTailSlots * 4;              // uint16 [1024]
     static constexpr int kWcls = kFail + kTailSlots * 2;            // uint8 [1024]
@@ -121,7 +131,7 @@ struct TailLds {
 };
 static_assert(TailLds::kBk + kTailBandCap * 8 - TailLds::kUnion <= TailLds::kUnionBytes, "phase-C scratch exceeds the union");
 static_assert(kTailGroups * kSegWords<8> * 4 <= TailLds::kUnionBytes, "segment lists exceed the union");
-static_assert(TailLds::kTotal <= 160 * 1024, "LDS budget of one CU");
+static_assert(TailLds::kTotal * kTailWgsPerCu <= 160 * 1024, "LDS budget of one CU");
 constexpr int kTailLdsBytes = TailLds::kTotal;
 
 __device__ __forceinline__ double tail_ld_f64(const double* p) {
@@ -424,7 +434,7 @@ __device__ __noinline__ void tail_solve_update_gicp(IterState* sit, const double
 }
 
 template <bool kGicp>
-__global__ void __launch_bounds__(kTailThreads)
+__global__ void __launch_bounds__(kTailThreads, (kTailThreads / 256) * kTailWgsPerCu)   // (threads, waves per SIMD)
 k_tail(const float4* __restrict__ src, const float4* __restrict__ src_nrm /* GICP: the reading's covariances, 2 x float4 */,
        IterState* __restrict__ it_g, Grid g, const float4* __restrict__ tgt_nrm /* GICP: the reference's covariances */,
        FilterCfg f, int* __restrict__ pos_io, float* __restrict__ d2_out,
@@ -513,8 +523,8 @@ k_tail(const float4* __restrict__ src, const float4* __restrict__ src_nrm /* GIC
         hnt[sl] = hint_g ? hint_g[q[u]] : (uint8_t)0;
         d2s[sl] = INFINITY;
         wcls[sl] = 0;
-        hist[sl] = 0u;
     }
+    for (int k = t; k < kTailBins; k += kTailThreads) hist[k] = 0u;
     if (t < 16) misc[t] = 0u;
     __syncthreads();
     if (sit->done || sit->stall) return;   // workgroup-uniform: an earlier sequence ended or stalled the loop
@@ -891,23 +901,26 @@ k_tail(const float4* __restrict__ src, const float4* __restrict__ src_nrm /* GIC
             // ---- coarse counts of all workgroups -> hist[0..255]; thread t sums word t & 63 (4 bins) of rows t >> 6, + 8, ...
             {
                 const unsigned* wbase = reinterpret_cast<const unsigned*>(hist_g + (size_t)buf * nwg * kTailHistRow) + (tv & 63);
-                constexpr int kG = kTailThreads / 64, kL = 256 / kG;
-                unsigned wv2[kL];
-#pragma unroll
-                for (int u = 0; u < kL; ++u) {
-                    const int b2 = (tv >> 6) + kG * u;
-                    wv2[u] = b2 < nwg ? tail_ld_u32(wbase + (size_t)b2 * (kTailHistRow * 2)) : 0u;
-                }
+                constexpr int kG = kTailThreads / 64, kL = (256 * kTailWgsPerCu) / kG;   // (at most 256 CUs x workgroups per CU)
                 unsigned c4[4] = {0, 0, 0, 0};
                 bool sat = false;
+                // (eight loads in flight at a time: a register array of all kL words cost 32 - 64 registers)
+                for (int u0 = 0; u0 < kL; u0 += 8) {
+                    unsigned wv2[8];
 #pragma unroll
-                for (int u = 0; u < kL; ++u)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const unsigned bv = (wv2[u] >> (8 * j)) & 255u;
-                        sat = sat || bv == 255u;
-                        c4[j] += bv;
+                    for (int u = 0; u < 8; ++u) {
+                        const int b2 = (tv >> 6) + kG * (u0 + u);
+                        wv2[u] = b2 < nwg ? tail_ld_u32(wbase + (size_t)b2 * (kTailHistRow * 2)) : 0u;
                     }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const unsigned bv = (wv2[u] >> (8 * j)) & 255u;
+                            sat = sat || bv == 255u;
+                            c4[j] += bv;
+                        }
+                }
                 if (sat) misc[5] = 1u;
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -1136,14 +1149,25 @@ k_tail(const float4* __restrict__ src, const float4* __restrict__ src_nrm /* GIC
         d2_out[q[u]] = d2s[sl];
         if (w_out) w_out[q[u]] = w;
         if (hint_g) hint_g[q[u]] = hnt[sl];
-        if (exit_reason == 3) {
-            // out of this launch's iteration budget: the next launch continues from the rows as they stand (anchors, bounds,
-            // matched points and runner-ups of the kernel's own searches), not from what the last select-based iteration left --
-            // a point re-matched in here would otherwise re-enter with its new position next to its old point's row
-            cache[q[u]] = st_rows[sl];
-            cache[(size_t)n + q[u]] = tq;
-            cache[2 * (size_t)n + q[u]] = st_rows[2 * kTailSlots + sl];
-            cache[3 * (size_t)n + q[u]] = st_rows[3 * kTailSlots + sl];
+    }
+    if (exit_reason == 3) {
+        // Out of this launch's iteration budget: the next launch continues from the rows as they stand (anchors, bounds, matched
+        // points and runner-ups of the kernel's own searches), not from what the last select-based iteration left -- a point
+        // re-matched in here would otherwise re-enter with its new position next to its old point's row.
+        for (int sl = t; sl < kTailSlots; sl += kTailThreads) {
+            const int64_t oc = (int64_t)(sl >> 3) * cfg.wpc + wq;
+            const int64_t r_in = oc * 8 + (sl & 7);
+            int64_t qq;
+            if (cfg.tile > 0) {
+                const int64_t tl = oc / cfg.tile, rr = oc - tl * cfg.tile;
+                qq = ((tl * 8 + xcls) * cfg.tile + rr) * 8 + (sl & 7);
+            } else {
+                qq = (int64_t)xcls * cfg.chunk8 + r_in;
+            }
+            if (r_in < cfg.chunk8 && qq < n) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cache[(size_t)r * (size_t)n + qq] = st_rows[r * kTailSlots + sl];
+            }
         }
     }
     if (t == 0 && n_searched) atomicAdd(&sync[kTailSearchedWord], n_searched);
