@@ -214,8 +214,15 @@ def test_c2_full_size_gicp_registration_vs_oracle():
     gids, gd2, _ = reg.correspondences()
     tree = orc.KdTree(sc.tgt_xyz)
     reg.close()
-    # GICP works in the caller's frame (no centring): the last search ran at the pose BEFORE the last update, so only
-    # consistency is checked here -- every reported pair is a true nearest neighbour at SOME pose within the last step
+    # GICP works in the caller's frame (no centring).  Round 3: iterations 1 .. 19 ran inside the persistent tail kernel
+    # (k_tail<true>: coherence shortcut, its own searches, fp64 GICP factors); the ids / d2 it left are those of its LAST
+    # iteration, which ran at reg_result.T_iter_prev -- bit-exact against the kd-tree at that pose
+    assert res.n_tail_launches == 1 and res.n_tail_iterations == ITERS - 1
+    T_prev = np.array(res.T_iter_prev, np.float32).reshape(4, 4).T.copy()
+    ids_p, d2_p = tree.knn(sc.src_xyz, T_prev, max_dist=0.5, n_threads=NT)
+    assert np.array_equal(gids, ids_p), f"GICP tail, last iteration: {(gids != ids_p).sum()} ids differ"
+    assert np.array_equal(gd2.view(np.uint32), d2_p.view(np.uint32)), "GICP tail, last iteration: d2 not bit-exact"
+    assert res.n_matched == int((ids_p >= 0).sum())
     ids_o, d2_o = tree.knn(sc.src_xyz, T_last, max_dist=0.5, n_threads=NT)
     agree = float((gids == ids_o).mean())
     assert agree > 0.995, agree
