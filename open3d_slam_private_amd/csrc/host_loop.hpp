@@ -430,10 +430,22 @@ static bool tail_eligible(const reg_handle* h) {
 
 // Enqueue the tail for at most `max_iters` iterations; the kernel reports ONCE (sequence h->seq) when it leaves.
 static reg_status enqueue_tail(reg_handle* h, const TailPlan& pl, int max_iters, bool want_w) {
-    HIPCHK(h, h->i_tail_sync.reserve(kTailSyncBytes));
+    // Two copies of the counter / accumulator block: a launch works on one and its workgroup 0 zeroes the OTHER one when it
+    // leaves (nobody uses that one then: the launch before it, in stream order, is over) -- no memset launch (5 us) in front of
+    // every tail launch.  Zeroed by the host when first allocated and after any launch that ended in an error.
+    if (!h->i_tail_sync.p) h->tail_sync_dirty = true;
+    HIPCHK(h, h->i_tail_sync.reserve(2 * (size_t)kTailSyncBytes));
+    if (h->tail_sync_dirty) {
+        HIPCHK(h, hipMemsetAsync(h->i_tail_sync.p, 0, 2 * (size_t)kTailSyncBytes, h->stream));
+        h->tail_sync_dirty = false;
+    }
+    const int sync_slot = h->tail_sync_slot;
+    h->tail_sync_slot ^= 1;
+    h->tail_sync_last = sync_slot;
+    unsigned* const sync_cur = h->i_tail_sync.as<unsigned>() + (size_t)sync_slot * (kTailSyncBytes / 4);
+    unsigned* const sync_next = h->i_tail_sync.as<unsigned>() + (size_t)(sync_slot ^ 1) * (kTailSyncBytes / 4);
     HIPCHK(h, h->i_tail_rows.reserve((size_t)2 * pl.grid * kTailHistRow * 8));
     HIPCHK(h, h->i_tail_band.reserve((size_t)2 * kTailBandCap * kTailRec * 4));
-    HIPCHK(h, hipMemsetAsync(h->i_tail_sync.p, 0, kTailSyncBytes, h->stream));
     const FilterCfg f = make_filter_cfg(h, 0);
     TailCfg cfg;
     cfg.n = h->n;
@@ -456,7 +468,7 @@ static reg_status enqueue_tail(reg_handle* h, const TailPlan& pl, int max_iters,
         auto go = [&](auto kernel) {
             launch(kernel, dim3(pl.grid), dim3(kTailThreads), (const float4*)h->s_xyz.as<float4>(), s_attr, h->i_iter.as<IterState>(),
                    h->grid, t_attr, f, h->i_pos.as<int>(), h->i_d2.as<float>(), w, hint, h->i_cache.as<float4>(),
-                   h->i_tail_sync.as<unsigned>(), h->i_tail_rows.as<double>(), h->i_tail_band.as<float>(), h->d_mirror, cfg);
+                   sync_cur, h->i_tail_rows.as<double>(), h->i_tail_band.as<float>(), h->d_mirror, cfg, sync_next);
         };
         if (gicp)
             go(k_tail<true>);
@@ -708,6 +720,7 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
                     const hipError_t e = hipStreamQuery(h->stream);
                     if (e == hipSuccess) break;
                     if (e != hipErrorNotReady) {
+                        h->tail_sync_dirty = true;
                         h->err = std::string("device fault while waiting for the tail kernel: ") + hipGetErrorString(e);
                         return REG_DEVICE_ERROR;
                     }
@@ -716,8 +729,10 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
             const bool reported = mirror_seq(h) >= tail_seq;
             unsigned words[4] = {0, 0, 0, 0};
             if (!reported || h->env.coh_stats || mir->status == REG_DEVICE_ERROR)
-                (void)hipMemcpy(words, h->i_tail_sync.as<unsigned>() + kTailErrWord, sizeof(words), hipMemcpyDeviceToHost);
+                (void)hipMemcpy(words, h->i_tail_sync.as<unsigned>() + (size_t)h->tail_sync_last * (kTailSyncBytes / 4) + kTailErrWord, sizeof(words),
+                                 hipMemcpyDeviceToHost);
             if (words[0] != 0 || (reported && mir->status == REG_DEVICE_ERROR)) {
+                h->tail_sync_dirty = true;
                 h->err = "persistent tail kernel: a grid barrier timed out (workgroups not co-resident? another process "
                          "running a persistent kernel on this GPU?); set O3D_NO_TAIL=1 to use the three-launch iteration";
                 return REG_DEVICE_ERROR;
@@ -730,7 +745,8 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
 #if O3D_TAIL_STAMPS
             {
                 unsigned long long st[24];
-                (void)hipMemcpy(st, h->i_tail_sync.as<unsigned>() + kTailStampWord, sizeof(st), hipMemcpyDeviceToHost);
+                (void)hipMemcpy(st, h->i_tail_sync.as<unsigned>() + (size_t)h->tail_sync_last * (kTailSyncBytes / 4) + kTailStampWord, sizeof(st),
+                                 hipMemcpyDeviceToHost);
                 const double it_n = std::max(1, reported ? mir->pad3 : 1);
                 static const char* names[12] = {"check", "search", "epilogue", "bandrec+comps", "sum+publish+drain", "arrive+wait", "row sums",
                                                 "band-stage", "band-scan", "band-rank", "band-add", "solve+update"};

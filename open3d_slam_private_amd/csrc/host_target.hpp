@@ -157,6 +157,8 @@ struct reg_handle {
     int last_stalls = 0;
     int64_t n_total_hint = 0;   // multi-GPU: points of the WHOLE reading (fitness of the GICP stop rule); 0: this handle's n
     int match_launches = 0;   // search launches since the reading was prepared (picks the XCD tile)
+    int tail_sync_slot = 0, tail_sync_last = 0;   // which copy of the tail kernel's counter block the next / the last launch uses
+    bool tail_sync_dirty = true;
     int last_tail_launches = 0, last_tail_iters = 0;   // persistent tail: launches / iterations of the last reg_register
     DevBuf i_tail_sync, i_tail_rows, i_tail_band;      // persistent tail: counters | per-workgroup sum rows | band records
     unsigned long long dist_seq0 = 0;

@@ -60,13 +60,13 @@ constexpr int kTailHistRow = 32;       // doubles per workgroup in the coarse-hi
 constexpr int kTailCoarse = 256;       // coarse bins of a wide band (second exchange of the iteration: see k_tail)
 constexpr float kTailWideRel = 0.02f;  // a band wider than this fraction of its lower edge takes the two-exchange form
 constexpr int kTailMaxIters = 64;      // iterations per launch
-constexpr int kTailSyncWords = 256;    // zeroed before every launch: arrival counters, record counters, error word, statistics
+constexpr int kTailSyncWords = 256;    // zero when a launch starts: arrival counters, record counters, error word, statistics
 constexpr int kTailRing = 4;           // epochs an accumulator set / record counter lives before it is reused
 constexpr int kTailBandCntWord = 128;  // record counter of epoch e: word [128 + 16 * (e % 4)]
 constexpr int kTailAccRows = 16;       // accumulator rows per epoch: same-address fp64 atomics serialise (~40 ns each, measured:
                                        // 256 waves on 8 rows cost the exchange 4 us), so one atomic per WORKGROUP on 16 rows
 constexpr int kTailAccDoubles = kTailRing * kTailAccRows * kSums;   // accumulators behind the sync words: [epoch % 4][row][32]
-constexpr int kTailSyncBytes = kTailSyncWords * 4 + kTailAccDoubles * 8;   // the block the host zeroes before every launch
+constexpr int kTailSyncBytes = kTailSyncWords * 4 + kTailAccDoubles * 8;   // the block a launch finds zeroed (two copies: workgroup 0 of a launch zeroes the other one on its way out)
 constexpr int kTailArriveStride = 16;  // arrival counters 64 bytes apart: word [x * 16], x = XCD class 0..7
 constexpr int kTailErrWord = 192;      // != 0: a grid barrier timed out
 constexpr int kTailSearchedWord = 193; // statistics: points searched (summed over iterations and workgroups)
@@ -440,7 +440,7 @@ k_tail(const float4* __restrict__ src, const float4* __restrict__ src_nrm /* GIC
        FilterCfg f, int* __restrict__ pos_io, float* __restrict__ d2_out,
        float* __restrict__ w_out, uint8_t* __restrict__ hint_g, float4* __restrict__ cache, unsigned* __restrict__ sync,
        double* __restrict__ hist_g /* [2][grid][kTailHistRow] */, float* __restrict__ band_g /* [2][kTailBandCap][12] */,
-       HostMirror* host, TailCfg cfg) {
+       HostMirror* host, TailCfg cfg, unsigned* __restrict__ sync_next /* the counter block of the NEXT launch: zeroed on the way out */) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float4* const st_rows = reinterpret_cast<float4*>(lds + TailLds::kRows);            // [row * kTailSlots + slot]
     uint32_t* const seg_lds = reinterpret_cast<uint32_t*>(lds + TailLds::kUnion);
@@ -527,7 +527,11 @@ k_tail(const float4* __restrict__ src, const float4* __restrict__ src_nrm /* GIC
     for (int k = t; k < kTailBins; k += kTailThreads) hist[k] = 0u;
     if (t < 16) misc[t] = 0u;
     __syncthreads();
-    if (sit->done || sit->stall) return;   // workgroup-uniform: an earlier sequence ended or stalled the loop
+    if (sit->done || sit->stall) {   // workgroup-uniform: an earlier sequence ended or stalled the loop
+        if (blockIdx.x == 0)
+            for (int w2 = t; w2 < kTailSyncBytes / 4; w2 += kTailThreads) sync_next[w2] = 0u;   // (as on the regular way out)
+        return;
+    }
     const unsigned cnt_lane = lane < 8 ? (unsigned)((nwg - lane + 7) >> 3) : 0u;   // workgroups of XCD class `lane`
     unsigned n_searched = 0;
     int exit_reason = 0;   // 1 done, 2 stall, 3 iteration budget of this launch, 4 barrier timeout
@@ -1178,6 +1182,7 @@ k_tail(const float4* __restrict__ src, const float4* __restrict__ src_nrm /* GIC
     }
 #endif
     if (blockIdx.x != 0) return;
+    for (int w2 = t; w2 < kTailSyncBytes / 4; w2 += kTailThreads) sync_next[w2] = 0u;
     if (t == 0) sync[kTailItersWord] = (unsigned)k_local;
     if (wave != 0) return;
     if (lane == 0) {
