@@ -697,7 +697,12 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
     const bool use_tail = tail_pl.ok && tail_lock.owns_lock();
     // The tail kernel copes with a limit that still moves (wide bands cost it a second exchange, not a stall): it takes over as
     // soon as the predicted band (at most +-60 % around the last limit) can be expected to hold the next one
-    if (use_tail) settle_tol = h->env.tail_settle_tol;
+    // ... but only where it can pay: with a fixed iteration count always; with the checkers deciding (the mapper's registrations:
+    // 4 - 7 iterations) not before tail_min_iters iterations have run without convergence -- a launch behind the iteration that
+    // converges, or for one or two early iterations, costs more than the three-launch iteration it replaces
+    // (tools/tools_checker_priors.py: 60 k -> 600 k, 3.6 / 4.1 / 6.9 iterations: +8 / +6 / +13 % with an unconditional tail)
+    const int tail_min_iters = fixed > 0 ? 0 : h->env.tail_min_iters;
+    const float fused_settle_tol = settle_tol;
     unsigned long long tail_seq = 0;   // != 0: a tail launch is in flight; nothing is enqueued behind it
     h->last_tail_launches = 0;
     h->last_tail_iters = 0;
@@ -737,7 +742,10 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
                          "running a persistent kernel on this GPU?); set O3D_NO_TAIL=1 to use the three-launch iteration";
                 return REG_DEVICE_ERROR;
             }
-            if (!reported) acked = h->seq;   // the stream drained without a report: the tail found the loop done / stalled
+            // The stream drained without a report: the tail found the loop done -- or STALLED by a three-launch iteration in front of
+            // it (checker mode runs those until tail_min_iters): that stall is still to be repaired by the branch below, so it must not
+            // be acknowledged here (the next tail launch would leave at once again, for ever).
+            if (!reported && !(mir->stall && std::max(mirror_seq(h), seq0) > acked)) acked = h->seq;
             if (h->env.coh_stats)
                 fprintf(stderr, "[o3dreg] tail launch: %u iterations, %u point searches (%.2f %% of the point-iterations)\n", words[2],
                         words[1], words[2] ? 100.0 * words[1] / ((double)words[2] * (double)h->n) : 0.0);
@@ -785,17 +793,19 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
             // fused iteration is the expensive one -- its band is as wide as the limit still moves (wide band -> histogram
             // select in the update kernel, many coherence failures) -- so starting too early costs more than another
             // select-based iteration (round-2 sweep, DESIGN.md 6.0: 25 % -> 5 %: C3 1.653 -> 1.574 ms)
+            const bool tail_now = use_tail && completed + inflight >= tail_min_iters;
+            settle_tol = tail_now ? h->env.tail_settle_tol : fused_settle_tol;
             bool settled = true;
             if (trimming) {
                 settled = any && mir->limit_prev < INFINITY && mir->limit_last < INFINITY &&
                           std::fabs(mir->limit_last - mir->limit_prev) <= settle_tol * mir->limit_last;
             }
             const auto tq0 = std::chrono::steady_clock::now();
-            const bool go_generic = !(can_fuse || use_tail) || generic_left > 0 || !settled;
+            const bool go_generic = !(can_fuse || tail_now) || generic_left > 0 || !settled;
             if (go_generic) {
                 s = enqueue_iteration(h, true);   // weights are always written: reg_get_correspondences reports them
                 if (generic_left > 0) --generic_left;
-            } else if (use_tail) {
+            } else if (tail_now) {
                 // the rest of the registration in ONE launch (it leaves when done, stalled, or out of its iteration budget)
                 s = enqueue_tail(h, tail_pl, limit - (completed + inflight), true);
                 tail_seq = h->seq;
@@ -812,7 +822,7 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
                 const auto tq1 = std::chrono::steady_clock::now();
                 fprintf(stderr, "[o3dreg] t=%.1fus enqueue seq %llu (%s) took %.1fus; mirror at %llu\n",
                         std::chrono::duration<double, std::micro>(tq0 - t_loop0).count(), h->seq - seq0,
-                        go_generic ? "generic" : (use_tail ? "tail" : "fused"), std::chrono::duration<double, std::micro>(tq1 - tq0).count(),
+                        go_generic ? "generic" : (tail_now ? "tail" : "fused"), std::chrono::duration<double, std::micro>(tq1 - tq0).count(),
                         std::max(mirror_seq(h), seq0) - seq0);
             }
             if (s != REG_OK) return s;

@@ -1120,11 +1120,13 @@ def test_gicp_open3d_convergence_criteria_iteration_count_and_pose_equal_the_ora
     assert g.relative_fitness_ == 1e-6 and g.relative_rmse_ == 1e-6
 
 
-def test_persistent_tail_equals_three_launch_iteration_and_select_based_path():
+def test_persistent_tail_equals_three_launch_iteration_and_select_based_path(monkeypatch):
     """The persistent settled-tail kernel (default), the three-launch fused iteration (debug_flags 128) and the select-based
     path (disable_fused) give the same iteration counts, ids, d2, weights (bit for bit) and poses -- on sizes that exercise
     1 .. 256 workgroups of the tail kernel, partially filled octets, narrow and wide bands (fixed count from iteration 2 on),
-    checker mode, maxDist-limited matching and no trimming at all."""
+    checker mode, maxDist-limited matching and no trimming at all.  (O3D_TAIL_MIN_ITERS = 0: in checker mode the tail otherwise
+    waits for six iterations -- the policy has its own test below; here the kernel itself is what is exercised.)"""
+    monkeypatch.setenv("O3D_TAIL_MIN_ITERS", "0")
     cases = [(37, 50, dict(fixed_iters=8, max_dist=float("inf"))), (300, 2000, dict(fixed_iters=9, max_dist=2.0)), (3000, 30000, dict(fixed_iters=12)), (24000, 240000, dict()),
              (24000, 240000, dict(fixed_iters=15, trim_ratio=0.6)), (9000, 90000, dict(fixed_iters=10, use_trimmed=0)),
              (9000, 90000, dict(max_dist=0.12)), (70001, 400000, dict(fixed_iters=14))]
@@ -1144,6 +1146,25 @@ def test_persistent_tail_equals_three_launch_iteration_and_select_based_path():
             assert np.array_equal(ids, ref[2]) and np.array_equal(d2.view(np.uint32), ref[3].view(np.uint32)), (n_src, kw, dbg)
             assert np.array_equal(w, ref[4]), (n_src, kw, dbg)
             assert np.abs(T - ref[0]).max() <= 2e-6, (n_src, kw, dbg, np.abs(T - ref[0]).max())
+
+
+def test_tail_entry_policy_in_checker_mode():
+    """With the checkers deciding (the mapper's registrations) the tail kernel may only take over after tail_min_iters (6)
+    iterations: a registration that converges in 4 - 5 iterations never launches it (a launch behind the converging iteration costs
+    more than it saves, tools/tools_checker_priors.py), a long one does; with a fixed count it takes over as soon as the trimmed
+    limit allows.  Poses equal the select-based path's either way."""
+    sc = synth.make_scene(24000, 240000, seed=90)
+    Ts, rs, *_ = _register(sc)                                   # checker mode, converges quickly
+    Tg, rg, *_ = _register(sc, disable_fused=1)
+    assert rs.iterations == rg.iterations and rs.iterations <= 6 and rs.n_tail_launches == 0
+    assert np.abs(Ts - Tg).max() <= 2e-6
+    Tf, rf, *_ = _register(sc, fixed_iters=12)
+    assert rf.n_tail_launches >= 1 and rf.n_tail_iterations >= 5
+    # a registration the checkers let run long (tight limits): the tail takes over after the sixth iteration
+    Tl, rl, *_ = _register(sc, min_diff_rot=1e-9, min_diff_trans=1e-9, max_iter=25)
+    Tlg, rlg, *_ = _register(sc, min_diff_rot=1e-9, min_diff_trans=1e-9, max_iter=25, disable_fused=1)
+    assert rl.iterations == rlg.iterations and rl.iterations >= 10 and rl.n_tail_launches >= 1
+    assert np.abs(Tl - Tlg).max() <= 2e-6
 
 
 def test_persistent_tail_stall_and_repair_and_iteration_budget():
@@ -1180,13 +1201,15 @@ def _register_gicp(sc, max_dist=0.5, **over):
     return T, res, ids, d2, w
 
 
-def test_gicp_persistent_tail_equals_the_select_based_gicp_iteration():
+def test_gicp_persistent_tail_equals_the_select_based_gicp_iteration(monkeypatch):
     """GICP (B1) with the coherence shortcut: from its second iteration on the registration runs inside the persistent tail
     kernel (k_tail<true>: per-point shortcut test, own searches, the fp64 GICP factor of k_linearize_gicp, one exchange, the
     GICP solve / se(3) update / stop rules on every workgroup).  Against the select-based iteration (disable_fused): same
     iteration count and flags, ids and d2 of the last evaluation bit for bit (the shortcut never changes a match), poses
     within 1e-6 (the 32 fp64 sums are added in a different order) -- for the epsilon rule, Open3D's relative rule, a run cut
-    off by max_iter, a fixed count, and sizes from one workgroup to all 256."""
+    off by max_iter, a fixed count, and sizes from one workgroup to all 256.  (O3D_TAIL_MIN_ITERS = 0: see
+    test_tail_entry_policy_in_checker_mode.)"""
+    monkeypatch.setenv("O3D_TAIL_MIN_ITERS", "0")
     cases = [(60, 300, dict(fixed_iters=6, max_dist=2.0)), (700, 9000, dict(max_iter=30)), (6000, 60000, dict(max_iter=30)),
              (6000, 60000, dict(max_iter=40, gicp_stop_rule=1)), (6000, 60000, dict(max_iter=4, gicp_stop_rule=1)),
              (6000, 60000, dict(max_iter=3)), (24000, 240000, dict(fixed_iters=12)),
