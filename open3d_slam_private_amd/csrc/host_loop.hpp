@@ -428,6 +428,22 @@ static bool tail_eligible(const reg_handle* h) {
            tail_plan(h).ok;
 }
 
+// Size of the last pose update as the host mirror shows it: translation of (T T_prev^-1) and its rotation angle (small-angle: the
+// norm of the skew part).  Row-major 4x4, rigid.
+static void last_step_motion(const HostMirror* m, float* trans, float* rot) {
+    const float* A = m->T;
+    const float* B = m->T_prev;
+    // D = A * inv(B), inv(B) = [Rb^T, -Rb^T tb]
+    float R[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) R[3 * i + j] = A[4 * i + 0] * B[4 * j + 0] + A[4 * i + 1] * B[4 * j + 1] + A[4 * i + 2] * B[4 * j + 2];
+    float t[3];
+    for (int i = 0; i < 3; ++i) t[i] = A[4 * i + 3] - (R[3 * i + 0] * B[3] + R[3 * i + 1] * B[7] + R[3 * i + 2] * B[11]);
+    *trans = std::sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
+    const float sx = 0.5f * (R[7] - R[5]), sy = 0.5f * (R[2] - R[6]), sz = 0.5f * (R[3] - R[1]);
+    *rot = std::sqrt(sx * sx + sy * sy + sz * sz);
+}
+
 // Enqueue the tail for at most `max_iters` iterations; the kernel reports ONCE (sequence h->seq) when it leaves.
 static reg_status enqueue_tail(reg_handle* h, const TailPlan& pl, int max_iters, bool want_w) {
     // Two copies of the counter / accumulator block: a launch works on one and its workgroup 0 zeroes the OTHER one when it
@@ -706,6 +722,7 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
     const int tail_min_iters = fixed > 0 ? 0 : h->env.tail_min_iters;
     const float fused_settle_tol = settle_tol;
     unsigned long long tail_seq = 0;   // != 0: a tail launch is in flight; nothing is enqueued behind it
+    bool tail_off = false;
     h->last_tail_launches = 0;
     h->last_tail_iters = 0;
     for (;;) {
@@ -749,9 +766,13 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
             // be acknowledged here (the next tail launch would leave at once again, for ever).
             if (!reported && !(mir->stall && std::max(mirror_seq(h), seq0) > acked)) acked = h->seq;
             if (h->env.coh_stats)
-                fprintf(stderr, "[o3dreg] tail launch: %u iterations, %u point searches (%.2f %% of the point-iterations)\n", words[2],
-                        words[1], words[2] ? 100.0 * words[1] / ((double)words[2] * (double)h->n) : 0.0);
+                fprintf(stderr, "[o3dreg] tail launch: %u iterations, %u point searches (%.2f %% of the point-iterations), stall cause %u\n", words[2],
+                        words[1], words[2] ? 100.0 * words[1] / ((double)words[2] * (double)h->n) : 0.0, words[3]);
             if (reported) h->last_tail_iters += mir->pad3;
+            // checker mode: a tail launch that stalled (the trimmed limit left even the +-60 % band: the registration is still in
+            // its fast phase) is not tried again in this registration -- the repair and the three-launch iterations carry on
+            // (far priors at C3 size: 1.15 launches and 0.53 stalls per registration otherwise, tools/tools_checker_priors.py)
+            if (reported && mir->stall && fixed <= 0) tail_off = true;
 #if O3D_TAIL_STAMPS
             {
                 unsigned long long st[24];
@@ -783,9 +804,11 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
         }
         if (trace && m_seq != last_traced) {
             last_traced = m_seq;
-            fprintf(stderr, "[o3dreg] seq %llu iter %d stall %d band_n %d limit %.6g prev %.6g band [%.6g, %.6g)\n",
+            float mt = 0.f, mr = 0.f;
+            last_step_motion(mir, &mt, &mr);
+            fprintf(stderr, "[o3dreg] seq %llu iter %d stall %d band_n %d limit %.6g prev %.6g band [%.6g, %.6g) step %.2e m %.2e rad\n",
                     m_seq - seq0, mir->iterations, mir->stall, mir->stall ? mir->band_count : mir->pad_nband, mir->limit_last, mir->limit_prev,
-                    mir->band_lo, mir->band_hi);
+                    mir->band_lo, mir->band_hi, mt, mr);
         }
         acked = std::max(acked, m_seq);
         const int completed = any ? mir->iterations : 0;
@@ -795,12 +818,21 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
             // fused iteration is the expensive one -- its band is as wide as the limit still moves (wide band -> histogram
             // select in the update kernel, many coherence failures) -- so starting too early costs more than another
             // select-based iteration (round-2 sweep, DESIGN.md 6.0: 25 % -> 5 %: C3 1.653 -> 1.574 ms)
-            const bool tail_now = use_tail && completed + inflight >= tail_min_iters;
+            const bool tail_now = use_tail && !tail_off && completed + inflight >= tail_min_iters;
             settle_tol = tail_now ? h->env.tail_settle_tol : fused_settle_tol;
             bool settled = true;
             if (trimming) {
                 settled = any && mir->limit_prev < INFINITY && mir->limit_last < INFINITY &&
                           std::fabs(mir->limit_last - mir->limit_prev) <= settle_tol * mir->limit_last;
+            }
+            // ... and the pose must have stopped jumping: a registration from a far prior sits on a plateau of the trimmed limit (most
+            // pairs at the matching radius) while it still turns by degrees per iteration, then the limit collapses 10 - 20 x within
+            // one iteration -- a band predicted on the plateau stalls there, and a tail launch entered there searches every point
+            // first (O3D_TRACE: 2.5e-2 rad steps at a limit moving by 1 %; the benchmark's registration enters at 6e-4 rad / 4 mm)
+            if (settled && any && (p2pl || fixed <= 0) && (can_fuse || tail_now)) {
+                float mt = 0.f, mr = 0.f;
+                last_step_motion(mir, &mt, &mr);
+                if (mt > h->env.settle_trans || mr > h->env.settle_rot) settled = false;
             }
             const auto tq0 = std::chrono::steady_clock::now();
             const bool go_generic = !(can_fuse || tail_now) || generic_left > 0 || !settled;

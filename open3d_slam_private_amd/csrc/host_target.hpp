@@ -48,6 +48,8 @@ struct EnvSwitches {
     float tail_timeout_s = 2.f; // O3D_TAIL_TIMEOUT_S: bound of every grid barrier of the tail kernel
     int xcd_tile_first = 32;      // O3D_XCD_TILE_FIRST / _LATER: workgroups per XCD tile of the search kernel, first two launches of a
     int xcd_tile_later = 16;      //   registration / later ones (0: one contiguous eighth of the reading per XCD)
+    float settle_trans = 0.02f;   // O3D_SETTLE_TRANS / O3D_SETTLE_ROT: largest last pose step [m] / [rad] at which the band-predicting iterations
+    float settle_rot = 4e-3f;     //   (three-launch, tail kernel) may take over from the select-based ones
     int tail_min_iters = 6;       // O3D_TAIL_MIN_ITERS: checker mode (no fixed count): iterations that must have run before the tail kernel may take over
     int tail_tile = 0;            // O3D_TAIL_TILE: octets per XCD tile of the tail kernel's slot mapping (0: contiguous eighths)
     bool no_gicp_tail = false;    // O3D_NO_GICP_TAIL=1: GICP stays on its select-based iteration
@@ -80,6 +82,8 @@ struct EnvSwitches {
         if (const char* v = getenv("O3D_NO_GICP_TAIL")) no_gicp_tail = atoi(v) != 0;
         if (const char* v = getenv("O3D_TAIL_TILE")) tail_tile = std::max(0, atoi(v));
         if (const char* v = getenv("O3D_TAIL_MIN_ITERS")) tail_min_iters = std::max(0, atoi(v));
+        if (const char* v = getenv("O3D_SETTLE_TRANS")) settle_trans = (float)atof(v);
+        if (const char* v = getenv("O3D_SETTLE_ROT")) settle_rot = (float)atof(v);
         if (const char* v = getenv("O3D_XCD_TILE_FIRST")) xcd_tile_first = std::max(0, atoi(v));
         if (const char* v = getenv("O3D_XCD_TILE_LATER")) xcd_tile_later = std::max(0, atoi(v));
         if (const char* v = getenv("O3D_GICP_TAIL_AFTER")) gicp_tail_after = atoi(v);

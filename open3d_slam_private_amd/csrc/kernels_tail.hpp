@@ -71,6 +71,8 @@ constexpr int kTailArriveStride = 16;  // arrival counters 64 bytes apart: word 
 constexpr int kTailErrWord = 192;      // != 0: a grid barrier timed out
 constexpr int kTailSearchedWord = 193; // statistics: points searched (summed over iterations and workgroups)
 constexpr int kTailItersWord = 194;    // statistics: iterations run by this launch (workgroup 0)
+constexpr int kTailCauseWord = 195;    // statistics: why the launch stalled (workgroup 0): 1 a coarse count saturated its byte, 2 more band records than
+                                       // kTailBandCap, 4 the rank lies outside the predicted band (8: outside the wide band)
 constexpr int kTailStampWord = 200;    // O3D_TAIL_STAMPS builds: 12 x uint64 per-phase ticks (10 ns) of workgroup 0, then of the last workgroup
 constexpr int kTailGroups = kTailThreads / 8;   // searches per round
 constexpr int kTailBins = 1024;        // bins of the one-level select inside the band (two per thread)
@@ -1007,6 +1009,9 @@ k_tail(const float4* __restrict__ src, const float4* __restrict__ src_nrm /* GIC
             const uint32_t kq = trim_rank(n_finite, sit->trim_ratio);
             const bool ok = !stall && (n_finite == 0 || (!band_bad && n_below <= kq && kq < n_below + n_band));
             if (!ok) {   // workgroup- and grid-uniform
+                if (blockIdx.x == 0 && t == 0)
+                    sync[kTailCauseWord] = (misc[5] != 0u ? 1u : 0u) | (n_band_raw > (unsigned)kTailBandCap ? 2u : 0u) |
+                                           ((!stall && !band_bad) ? 4u : 0u) | ((stall && misc[5] == 0u) ? 8u : 0u);
                 exit_reason = 2;
                 break;
             }
