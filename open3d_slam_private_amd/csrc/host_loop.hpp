@@ -766,8 +766,8 @@ reg_status reg_register(reg_handle* h, const float T_init[16], float T_out[16], 
             // be acknowledged here (the next tail launch would leave at once again, for ever).
             if (!reported && !(mir->stall && std::max(mirror_seq(h), seq0) > acked)) acked = h->seq;
             if (h->env.coh_stats)
-                fprintf(stderr, "[o3dreg] tail launch: %u iterations, %u point searches (%.2f %% of the point-iterations), stall cause %u\n", words[2],
-                        words[1], words[2] ? 100.0 * words[1] / ((double)words[2] * (double)h->n) : 0.0, words[3]);
+                fprintf(stderr, "[o3dreg] tail launch: %u iterations, %u point searches (%.2f %% of the point-iterations), stall cause %u, band records of its last iteration %d\n", words[2],
+                        words[1], words[2] ? 100.0 * words[1] / ((double)words[2] * (double)h->n) : 0.0, words[3], reported ? mir->pad_nband : -1);
             if (reported) h->last_tail_iters += mir->pad3;
             // checker mode: a tail launch that stalled (the trimmed limit left even the +-60 % band: the registration is still in
             // its fast phase) is not tried again in this registration -- the repair and the three-launch iterations carry on
