@@ -480,6 +480,28 @@ def main():
         extras["shipped_checkers_near_prior"] = {"ms_per_registration": 1e3 * tn / x_steps, "iterations": int(nres.iterations),
                                                  "prior_error": "0.2 deg, 2 cm", "workload": workload,
                                                  "pose_vs_truth": {"trans_m": nt, "rot_rad": nr}}
+        # ... and from priors far off (3 deg / 25 cm, sigma per axis: 5 deg / 0.4 m typical): registrations that sit on a plateau of
+        #     the trimmed limit before they snap in -- the case the pose-step gate of the loop is for
+        frng = np.random.default_rng(1)
+        f_t, f_it, f_stalls = [], [], 0
+        for _ in range(12):
+            dT = np.eye(4)
+            dT[:3, :3] = synth.rpy_to_R(*frng.normal(scale=0.05, size=3))
+            dT[:3, 3] = frng.normal(scale=0.25, size=3)
+            T_far = (dT @ Tn).astype(np.float32)
+            creg.register(T_far)
+            torch.cuda.synchronize()
+            tf0 = time.perf_counter()
+            Tfr, fres = creg.register(T_far)
+            torch.cuda.synchronize()
+            f_t.append(time.perf_counter() - tf0)
+            f_it.append(int(fres.iterations))
+            f_stalls += int(fres.n_band_stalls)
+        extras["shipped_checkers_far_priors"] = {"ms_per_registration_mean": 1e3 * float(np.mean(f_t)),
+                                                 "ms_per_registration_median": 1e3 * float(np.median(f_t)),
+                                                 "iterations_mean": float(np.mean(f_it)), "band_stalls_per_registration": f_stalls / 12.0,
+                                                 "priors": "12 draws, rotation sigma 0.05 rad per axis, translation sigma 0.25 m per axis",
+                                                 "workload": workload}
         creg.close()
         # (1b) the GICP cost (the north star's cost function; parity unpinned) on the headline clouds
         if True:
