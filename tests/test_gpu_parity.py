@@ -1228,3 +1228,41 @@ def test_gicp_persistent_tail_equals_the_select_based_gicp_iteration(monkeypatch
         assert np.abs(Tt - Tg).max() <= 1e-6, (n_src, kw, np.abs(Tt - Tg).max())
         assert rt.n_matched == rg.n_matched and abs(rt.error - rg.error) <= 1e-9 * max(rg.error, 1e-30)
         assert np.allclose(np.array(rt.T_iter_prev), np.array(rg.T_iter_prev), atol=1e-6)
+
+
+def test_far_priors_in_checker_mode_wait_for_the_pose_to_calm_down(monkeypatch):
+    """Registrations from priors 3 deg / 25 cm off sit on a plateau of the trimmed limit while the pose still turns by 1e-2 rad per
+    iteration, then the limit collapses: band-predicting iterations (three-launch, tail kernel) started on the plateau stall there.
+    The loop therefore also looks at the last pose step (O3D_SETTLE_TRANS / _ROT).  Same poses and iteration counts as the
+    select-based path; (almost) no band stall with the gate, several without it."""
+    sc = synth.make_scene(24000, 240000, seed=91)
+    Tt = np.asarray(sc.T_true, np.float64)
+
+    def run(**over):
+        rng = np.random.default_rng(4)
+        p = capi.shipped_params()
+        for k, v in over.items():
+            setattr(p, k, v)
+        reg = capi.Registration(p)
+        reg.set_target(sc.tgt_xyz, sc.tgt_nrm)
+        reg.set_source(sc.src_xyz, sc.src_nrm)
+        out, stalls = [], 0
+        for _ in range(8):
+            dT = np.eye(4)
+            dT[:3, :3] = synth.rpy_to_R(*rng.normal(scale=0.05, size=3))
+            dT[:3, 3] = rng.normal(scale=0.25, size=3)
+            T, res = reg.register((dT @ Tt).astype(np.float32))
+            out.append((T, res.iterations))
+            stalls += res.n_band_stalls
+        reg.close()
+        return out, stalls
+
+    ref, _ = run(disable_fused=1)
+    gated, s_gated = run()
+    monkeypatch.setenv("O3D_SETTLE_TRANS", "10")
+    monkeypatch.setenv("O3D_SETTLE_ROT", "10")
+    ungated, s_ungated = run()
+    for (Ta, ia), (Tb, ib), (Tc, ic) in zip(ref, gated, ungated):
+        assert ia == ib == ic
+        assert np.abs(Ta - Tb).max() <= 2e-6 and np.abs(Ta - Tc).max() <= 2e-6
+    assert s_gated <= 1 and s_gated <= s_ungated, (s_gated, s_ungated)
