@@ -50,7 +50,7 @@ struct EnvSwitches {
     int xcd_tile_later = 16;      //   registration / later ones (0: one contiguous eighth of the reading per XCD)
     float settle_trans = 0.02f;   // O3D_SETTLE_TRANS / O3D_SETTLE_ROT: largest last pose step [m] / [rad] at which the band-predicting iterations
     float settle_rot = 4e-3f;     //   (three-launch, tail kernel) may take over from the select-based ones
-    int tail_min_iters = 6;       // O3D_TAIL_MIN_ITERS: checker mode (no fixed count): iterations that must have run before the tail kernel may take over
+    int tail_min_iters = 8;       // O3D_TAIL_MIN_ITERS: checker mode (no fixed count): iterations that must have run before the tail kernel may take over
     int tail_tile = 0;            // O3D_TAIL_TILE: octets per XCD tile of the tail kernel's slot mapping (0: contiguous eighths)
     bool no_gicp_tail = false;    // O3D_NO_GICP_TAIL=1: GICP stays on its select-based iteration
     int gicp_tail_after = 1;      // O3D_GICP_TAIL_AFTER: select-based GICP iterations before the tail kernel takes over

@@ -1125,7 +1125,7 @@ def test_persistent_tail_equals_three_launch_iteration_and_select_based_path(mon
     path (disable_fused) give the same iteration counts, ids, d2, weights (bit for bit) and poses -- on sizes that exercise
     1 .. 256 workgroups of the tail kernel, partially filled octets, narrow and wide bands (fixed count from iteration 2 on),
     checker mode, maxDist-limited matching and no trimming at all.  (O3D_TAIL_MIN_ITERS = 0: in checker mode the tail otherwise
-    waits for six iterations -- the policy has its own test below; here the kernel itself is what is exercised.)"""
+    waits for eight iterations -- the policy has its own test below; here the kernel itself is what is exercised.)"""
     monkeypatch.setenv("O3D_TAIL_MIN_ITERS", "0")
     cases = [(37, 50, dict(fixed_iters=8, max_dist=float("inf"))), (300, 2000, dict(fixed_iters=9, max_dist=2.0)), (3000, 30000, dict(fixed_iters=12)), (24000, 240000, dict()),
              (24000, 240000, dict(fixed_iters=15, trim_ratio=0.6)), (9000, 90000, dict(fixed_iters=10, use_trimmed=0)),
@@ -1149,7 +1149,7 @@ def test_persistent_tail_equals_three_launch_iteration_and_select_based_path(mon
 
 
 def test_tail_entry_policy_in_checker_mode():
-    """With the checkers deciding (the mapper's registrations) the tail kernel may only take over after tail_min_iters (6)
+    """With the checkers deciding (the mapper's registrations) the tail kernel may only take over after tail_min_iters (8)
     iterations: a registration that converges in 4 - 5 iterations never launches it (a launch behind the converging iteration costs
     more than it saves, tools/tools_checker_priors.py), a long one does; with a fixed count it takes over as soon as the trimmed
     limit allows.  Poses equal the select-based path's either way."""
@@ -1160,7 +1160,7 @@ def test_tail_entry_policy_in_checker_mode():
     assert np.abs(Ts - Tg).max() <= 2e-6
     Tf, rf, *_ = _register(sc, fixed_iters=12)
     assert rf.n_tail_launches >= 1 and rf.n_tail_iterations >= 5
-    # a registration the checkers let run long (tight limits): the tail takes over after the sixth iteration
+    # a registration the checkers let run long (tight limits): the tail takes over after the eighth iteration
     Tl, rl, *_ = _register(sc, min_diff_rot=1e-9, min_diff_trans=1e-9, max_iter=25)
     Tlg, rlg, *_ = _register(sc, min_diff_rot=1e-9, min_diff_trans=1e-9, max_iter=25, disable_fused=1)
     assert rl.iterations == rlg.iterations and rl.iterations >= 10 and rl.n_tail_launches >= 1
